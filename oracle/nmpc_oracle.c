@@ -1,0 +1,892 @@
+/*
+ * nmpc_oracle.c -- CPU ORACLE (test infrastructure, NOT the product).  See nmpc_oracle.h.
+ *
+ * Readable, dense, unstructured FP64 restatement of what acados does for the OCP that
+ * reference src/rotors_mpc_controller/controller.py:175-355 builds.  Deliberately written
+ * with generic dense loops (no sparsity exploitation, AoS, one instance at a time) so
+ * that it is an independent check of the structured SoA HIP kernels.
+ *
+ * [REF]      = follows /root/reference (file:line given).
+ * [UPSTREAM] = restates published acados / HPIPM behaviour (un-vendored, unpinned).
+ */
+#include "nmpc_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define NX ORC_NX
+#define NU ORC_NU
+#define NY ORC_NY
+
+/* ------------------------------------------------------------------------------------ */
+/* defaults: reference config/params.yaml:1-33 and controller.py:98-110                  */
+void orc_default_config(orc_config *c)
+{
+    static const double W[NY] = {10, 10, 8, 1, 1, 0.2, 3.2, 3.2, 3.2, 3.2, 1.4, 1.4, 0.4,
+                                 1.75, 1.75, 1.75, 1.75};
+    static const double We[NX] = {5, 5, 3, 2, 2, 2, 12, 12, 12, 18.5, 2, 2, 1.8};
+    const double L = 0.17, kf = 8.54858e-6, km = 0.016;
+    const double spin[NU] = {-1.0, 1.0, -1.0, 1.0};
+    const double rx[NU] = {L, 0.0, -L, 0.0}, ry[NU] = {0.0, L, 0.0, -L};
+    memset(c, 0, sizeof(*c));
+    c->N = 20;
+    c->dt = 0.05;
+    memcpy(c->W, W, sizeof(W));
+    memcpy(c->We, We, sizeof(We));
+    for (int i = 0; i < NU; i++) {
+        c->lbu[i] = kf * 50.0 * 50.0;   /* controller.py:105 */
+        c->ubu[i] = kf * 838.0 * 838.0; /* controller.py:106 */
+        c->rotor_x[i] = rx[i];
+        c->rotor_y[i] = ry[i];
+        c->rotor_z[i] = spin[i] * km;   /* controller.py:103 */
+    }
+    c->lm = 7.0e-3;
+    c->lm_scaled_by_dt = 1;
+    c->cost_scaled_by_dt = 1;
+    c->mass = 0.68;
+    c->gravity = 9.81;
+    c->J[0] = 0.007; c->J[1] = 0.007; c->J[2] = 0.012;
+    c->sim_num_stages = 2;
+    c->sim_num_steps = 2;
+    c->qp_iter_max = 600;
+    c->qp_cond_N = 0;
+    c->qp_tol_comp = 1e-11;
+    c->qp_tol_stat = 1e-11;
+    c->qp_mu0 = 0.1;
+    c->qp_tau = 0.995;
+    c->qp_thr0 = 0.1;
+    c->qp_thr0_rel = 0.25;
+    c->qp_gamma = 1e-3;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* model, [REF] controller.py:267-355                                                    */
+void orc_model_f(const orc_config *c, const double *x, const double *u, double *f)
+{
+    const double vx = x[3], vy = x[4], vz = x[5];
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const double wx = x[10], wy = x[11], wz = x[12];
+    /* third column of the rotation matrix, controller.py:296,299,302 */
+    const double r13 = 2.0 * (qx * qz + qw * qy);
+    const double r23 = 2.0 * (qy * qz - qw * qx);
+    const double r33 = 1.0 - 2.0 * (qx * qx + qy * qy);
+    const double T = (u[0] + u[1] + u[2] + u[3]) / c->mass; /* controller.py:310-313 */
+    f[0] = vx; f[1] = vy; f[2] = vz;
+    f[3] = r13 * T;
+    f[4] = r23 * T;
+    f[5] = r33 * T - c->gravity;                             /* controller.py:314 */
+    f[6] = 0.5 * (-qx * wx - qy * wy - qz * wz);             /* controller.py:316 */
+    f[7] = 0.5 * (qw * wx + qy * wz - qz * wy);              /* controller.py:317 */
+    f[8] = 0.5 * (qw * wy + qz * wx - qx * wz);              /* controller.py:318 */
+    f[9] = 0.5 * (qw * wz + qx * wy - qy * wx);              /* controller.py:319 */
+    double tx = 0, ty = 0, tz = 0;                           /* controller.py:326-328 */
+    for (int i = 0; i < NU; i++) {
+        tx += u[i] * c->rotor_y[i];
+        ty += u[i] * (-c->rotor_x[i]);
+        tz += u[i] * c->rotor_z[i];
+    }
+    const double Jx = c->J[0], Jy = c->J[1], Jz = c->J[2];
+    const double cx = wy * (Jz * wz) - wz * (Jy * wy);       /* controller.py:335 */
+    const double cy = wz * (Jx * wx) - wx * (Jz * wz);       /* controller.py:336 */
+    const double cz = wx * (Jy * wy) - wy * (Jx * wx);       /* controller.py:337 */
+    f[10] = (tx - cx) / Jx;                                  /* controller.py:339-341 */
+    f[11] = (ty - cy) / Jy;
+    f[12] = (tz - cz) / Jz;
+}
+
+/* hand-derived Jacobians of orc_model_f (checked against sympy in tests, K4) */
+void orc_model_jac(const orc_config *c, const double *x, const double *u, double *fx, double *fu)
+{
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    const double wx = x[10], wy = x[11], wz = x[12];
+    const double T = (u[0] + u[1] + u[2] + u[3]) / c->mass;
+    const double Jx = c->J[0], Jy = c->J[1], Jz = c->J[2];
+    memset(fx, 0, sizeof(double) * NX * NX);
+    memset(fu, 0, sizeof(double) * NX * NU);
+#define FX(r, cc) fx[(r) * NX + (cc)]
+#define FU(r, cc) fu[(r) * NU + (cc)]
+    FX(0, 3) = 1.0; FX(1, 4) = 1.0; FX(2, 5) = 1.0;
+    /* d vdot / d q */
+    FX(3, 6) = 2.0 * qy * T;  FX(3, 7) = 2.0 * qz * T;  FX(3, 8) = 2.0 * qw * T;  FX(3, 9) = 2.0 * qx * T;
+    FX(4, 6) = -2.0 * qx * T; FX(4, 7) = -2.0 * qw * T; FX(4, 8) = 2.0 * qz * T;  FX(4, 9) = 2.0 * qy * T;
+    FX(5, 7) = -4.0 * qx * T; FX(5, 8) = -4.0 * qy * T;
+    /* d qdot / d q */
+    FX(6, 7) = -0.5 * wx; FX(6, 8) = -0.5 * wy; FX(6, 9) = -0.5 * wz;
+    FX(7, 6) = 0.5 * wx;  FX(7, 8) = 0.5 * wz;  FX(7, 9) = -0.5 * wy;
+    FX(8, 6) = 0.5 * wy;  FX(8, 7) = -0.5 * wz; FX(8, 9) = 0.5 * wx;
+    FX(9, 6) = 0.5 * wz;  FX(9, 7) = 0.5 * wy;  FX(9, 8) = -0.5 * wx;
+    /* d qdot / d omega */
+    FX(6, 10) = -0.5 * qx; FX(6, 11) = -0.5 * qy; FX(6, 12) = -0.5 * qz;
+    FX(7, 10) = 0.5 * qw;  FX(7, 11) = -0.5 * qz; FX(7, 12) = 0.5 * qy;
+    FX(8, 10) = 0.5 * qz;  FX(8, 11) = 0.5 * qw;  FX(8, 12) = -0.5 * qx;
+    FX(9, 10) = -0.5 * qy; FX(9, 11) = 0.5 * qx;  FX(9, 12) = 0.5 * qw;
+    /* d omegadot / d omega : omegadot_x = (tx - (Jz-Jy) wy wz)/Jx etc. */
+    FX(10, 11) = -(Jz - Jy) * wz / Jx; FX(10, 12) = -(Jz - Jy) * wy / Jx;
+    FX(11, 10) = -(Jx - Jz) * wz / Jy; FX(11, 12) = -(Jx - Jz) * wx / Jy;
+    FX(12, 10) = -(Jy - Jx) * wy / Jz; FX(12, 11) = -(Jy - Jx) * wx / Jz;
+    const double r13 = 2.0 * (qx * qz + qw * qy);
+    const double r23 = 2.0 * (qy * qz - qw * qx);
+    const double r33 = 1.0 - 2.0 * (qx * qx + qy * qy);
+    for (int i = 0; i < NU; i++) {
+        FU(3, i) = r13 / c->mass;
+        FU(4, i) = r23 / c->mass;
+        FU(5, i) = r33 / c->mass;
+        FU(10, i) = c->rotor_y[i] / Jx;
+        FU(11, i) = -c->rotor_x[i] / Jy;
+        FU(12, i) = c->rotor_z[i] / Jz;
+    }
+#undef FX
+#undef FU
+}
+
+/* [UPSTREAM] counterpart of CasADi-generated <model>_expl_vde_forw:
+ * (x, Sx, Su, u) -> (f, fx*Sx, fx*Su + fu)                                              */
+void orc_vde_forw(const orc_config *c, const double *x, const double *Sx, const double *Su,
+                  const double *u, double *xdot, double *Sxdot, double *Sudot)
+{
+    double fx[NX * NX], fu[NX * NU];
+    orc_model_f(c, x, u, xdot);
+    orc_model_jac(c, x, u, fx, fu);
+    for (int i = 0; i < NX; i++) {
+        for (int j = 0; j < NX; j++) {
+            double s = 0.0;
+            for (int k = 0; k < NX; k++) s += fx[i * NX + k] * Sx[k * NX + j];
+            Sxdot[i * NX + j] = s;
+        }
+        for (int j = 0; j < NU; j++) {
+            double s = fu[i * NU + j];
+            for (int k = 0; k < NX; k++) s += fx[i * NX + k] * Su[k * NU + j];
+            Sudot[i * NU + j] = s;
+        }
+    }
+}
+
+/* [UPSTREAM] counterpart of <model>_expl_vde_adj: jtimes(f, [x;u], lam, transpose) */
+void orc_vde_adj(const orc_config *c, const double *x, const double *lam, const double *u,
+                 double *adj)
+{
+    double fx[NX * NX], fu[NX * NU];
+    orc_model_jac(c, x, u, fx, fu);
+    for (int j = 0; j < NX; j++) {
+        double s = 0.0;
+        for (int i = 0; i < NX; i++) s += fx[i * NX + j] * lam[i];
+        adj[j] = s;
+    }
+    for (int j = 0; j < NU; j++) {
+        double s = 0.0;
+        for (int i = 0; i < NX; i++) s += fu[i * NU + j] * lam[i];
+        adj[NX + j] = s;
+    }
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* [UPSTREAM] acados sim_erk: explicit RK on the forward VDE.  Tableaus as acados selects
+ * them from sim_method_num_stages: 1 Euler, 2 explicit midpoint, 3 Kutta-3, 4 RK4.       */
+static void erk_tableau(int ns, double *Arr /*ns*ns*/, double *brr, double *crr)
+{
+    memset(Arr, 0, sizeof(double) * 16);
+    memset(brr, 0, sizeof(double) * 4);
+    memset(crr, 0, sizeof(double) * 4);
+    switch (ns) {
+    case 1: brr[0] = 1.0; break;
+    case 2: Arr[1 * ns + 0] = 0.5; brr[1] = 1.0; crr[1] = 0.5; break;
+    case 3:
+        Arr[1 * ns + 0] = 0.5; Arr[2 * ns + 0] = -1.0; Arr[2 * ns + 1] = 2.0;
+        brr[0] = 1.0 / 6.0; brr[1] = 2.0 / 3.0; brr[2] = 1.0 / 6.0;
+        crr[1] = 0.5; crr[2] = 1.0; break;
+    default: /* 4 */
+        Arr[1 * 4 + 0] = 0.5; Arr[2 * 4 + 1] = 0.5; Arr[3 * 4 + 2] = 1.0;
+        brr[0] = 1.0 / 6.0; brr[1] = 1.0 / 3.0; brr[2] = 1.0 / 3.0; brr[3] = 1.0 / 6.0;
+        crr[1] = 0.5; crr[2] = 0.5; crr[3] = 1.0; break;
+    }
+}
+
+void orc_integrate(const orc_config *c, const double *x, const double *u,
+                   double *xn, double *A, double *B)
+{
+    int ns = c->sim_num_stages;
+    if (ns < 1 || ns > 4) ns = 4;
+    const int steps = c->sim_num_steps > 0 ? c->sim_num_steps : 1;
+    const double h = c->dt / steps;
+    double Arr[16], brr[4], crr[4];
+    erk_tableau(ns, Arr, brr, crr);
+    enum { NS = NX + NX * NX + NX * NU };
+    double z[NS], zs[NS], K[4][NS];
+    memcpy(z, x, sizeof(double) * NX);
+    memset(z + NX, 0, sizeof(double) * (NX * NX + NX * NU));
+    for (int i = 0; i < NX; i++) z[NX + i * NX + i] = 1.0; /* Sx(0) = I, Su(0) = 0 */
+    for (int st = 0; st < steps; st++) {
+        for (int s = 0; s < ns; s++) {
+            memcpy(zs, z, sizeof(z));
+            for (int j = 0; j < s; j++) {
+                const double a = h * Arr[s * ns + j];
+                if (a != 0.0)
+                    for (int i = 0; i < NS; i++) zs[i] += a * K[j][i];
+            }
+            orc_vde_forw(c, zs, zs + NX, zs + NX + NX * NX, u,
+                         K[s], K[s] + NX, K[s] + NX + NX * NX);
+        }
+        for (int s = 0; s < ns; s++) {
+            const double w = h * brr[s];
+            if (w != 0.0)
+                for (int i = 0; i < NS; i++) z[i] += w * K[s][i];
+        }
+    }
+    memcpy(xn, z, sizeof(double) * NX);
+    memcpy(A, z + NX, sizeof(double) * NX * NX);
+    memcpy(B, z + NX + NX * NX, sizeof(double) * NX * NU);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* [UPSTREAM] SQP_RTI preparation: dynamics linearisation + LINEAR_LS Gauss-Newton cost
+ * (U3, U4), Levenberg-Marquardt (U5), PROJECT_REDUC_HESS as a check (U6), input bounds
+ * shifted to the linearisation point.  Vx=[I;0], Vu=[0;I] (controller.py:226-235) make
+ * y = [x;u] and every Hessian block diagonal.                                           */
+void orc_linearize(const orc_config *c, const double *xtraj, const double *utraj,
+                   const double *yref, const double *yref_e,
+                   double *A, double *B, double *b, double *q, double *r,
+                   double *lo, double *hi, double *Qd, double *Rd, int *hess_projected)
+{
+    const int N = c->N;
+    int projected = 0;
+    for (int k = 0; k < N; k++) {
+        const double *xk = xtraj + k * NX, *uk = utraj + k * NU;
+        double xn[NX];
+        orc_integrate(c, xk, uk, xn, A + k * NX * NX, B + k * NX * NU);
+        for (int i = 0; i < NX; i++) b[k * NX + i] = xn[i] - xtraj[(k + 1) * NX + i];
+        const double sc = c->cost_scaled_by_dt ? c->dt : 1.0;
+        const double lmk = c->lm * (c->lm_scaled_by_dt ? c->dt : 1.0);
+        for (int i = 0; i < NX; i++) {
+            q[k * NX + i] = sc * c->W[i] * (xk[i] - yref[k * NY + i]);
+            Qd[k * NX + i] = sc * c->W[i] + lmk;
+            if (!(Qd[k * NX + i] > 0.0)) projected = 1;
+        }
+        for (int i = 0; i < NU; i++) {
+            r[k * NU + i] = sc * c->W[NX + i] * (uk[i] - yref[k * NY + NX + i]);
+            Rd[k * NU + i] = sc * c->W[NX + i] + lmk;
+            if (!(Rd[k * NU + i] > 0.0)) projected = 1;
+            lo[k * NU + i] = c->lbu[i] - uk[i];
+            hi[k * NU + i] = c->ubu[i] - uk[i];
+        }
+    }
+    for (int i = 0; i < NX; i++) {
+        q[N * NX + i] = c->We[i] * (xtraj[N * NX + i] - yref_e[i]);
+        Qd[N * NX + i] = c->We[i] + c->lm;
+        if (!(Qd[N * NX + i] > 0.0)) projected = 1;
+    }
+    if (hess_projected) *hess_projected = projected;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* generic OCP-QP with box bounds on the inputs only (dense stage Hessians, variable nu)  */
+typedef struct {
+    int N;
+    int *nu;
+    double **A, **B, **b;   /* A nx*nx, B nx*nu (row-major) */
+    double **Q, **R, **S;   /* Q nx*nx, R nu*nu, S nu*nx */
+    double **q, **r, **lo, **hi;
+    double *QN, *qN;        /* terminal nx*nx, nx */
+} ocpqp;
+
+static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+
+static void ocpqp_alloc(ocpqp *p, int N, const int *nu)
+{
+    p->N = N;
+    p->nu = (int *)malloc(sizeof(int) * (size_t)N);
+    p->A = (double **)malloc(sizeof(double *) * N); p->B = (double **)malloc(sizeof(double *) * N);
+    p->b = (double **)malloc(sizeof(double *) * N); p->Q = (double **)malloc(sizeof(double *) * N);
+    p->R = (double **)malloc(sizeof(double *) * N); p->S = (double **)malloc(sizeof(double *) * N);
+    p->q = (double **)malloc(sizeof(double *) * N); p->r = (double **)malloc(sizeof(double *) * N);
+    p->lo = (double **)malloc(sizeof(double *) * N); p->hi = (double **)malloc(sizeof(double *) * N);
+    for (int k = 0; k < N; k++) {
+        const int m = nu[k];
+        p->nu[k] = m;
+        p->A[k] = dalloc(NX * NX); p->B[k] = dalloc((size_t)NX * m); p->b[k] = dalloc(NX);
+        p->Q[k] = dalloc(NX * NX); p->R[k] = dalloc((size_t)m * m); p->S[k] = dalloc((size_t)m * NX);
+        p->q[k] = dalloc(NX); p->r[k] = dalloc(m); p->lo[k] = dalloc(m); p->hi[k] = dalloc(m);
+    }
+    p->QN = dalloc(NX * NX);
+    p->qN = dalloc(NX);
+}
+
+static void ocpqp_free(ocpqp *p)
+{
+    for (int k = 0; k < p->N; k++) {
+        free(p->A[k]); free(p->B[k]); free(p->b[k]); free(p->Q[k]); free(p->R[k]); free(p->S[k]);
+        free(p->q[k]); free(p->r[k]); free(p->lo[k]); free(p->hi[k]);
+    }
+    free(p->A); free(p->B); free(p->b); free(p->Q); free(p->R); free(p->S);
+    free(p->q); free(p->r); free(p->lo); free(p->hi); free(p->nu); free(p->QN); free(p->qN);
+}
+
+/* in-place lower Cholesky of an m*m row-major SPD matrix; returns 0 ok, 1 not SPD */
+static int chol_lower(double *M, int m)
+{
+    for (int j = 0; j < m; j++) {
+        double d = M[j * m + j];
+        for (int k = 0; k < j; k++) d -= M[j * m + k] * M[j * m + k];
+        if (!(d > 0.0)) return 1;
+        d = sqrt(d);
+        M[j * m + j] = d;
+        for (int i = j + 1; i < m; i++) {
+            double s = M[i * m + j];
+            for (int k = 0; k < j; k++) s -= M[i * m + k] * M[j * m + k];
+            M[i * m + j] = s / d;
+        }
+        for (int i = 0; i < j; i++) M[i * m + j] = 0.0;
+    }
+    return 0;
+}
+
+/* y := L^{-1} y (forward substitution), ncol right-hand sides stored row-major m*ncol */
+static void trsm_lower(const double *L, int m, double *Y, int ncol)
+{
+    for (int i = 0; i < m; i++) {
+        for (int cidx = 0; cidx < ncol; cidx++) {
+            double s = Y[i * ncol + cidx];
+            for (int k = 0; k < i; k++) s -= L[i * m + k] * Y[k * ncol + cidx];
+            Y[i * ncol + cidx] = s / L[i * m + i];
+        }
+    }
+}
+
+/* y := L^{-T} y for a single vector */
+static void trsv_lower_t(const double *L, int m, double *y)
+{
+    for (int i = m - 1; i >= 0; i--) {
+        double s = y[i];
+        for (int k = i + 1; k < m; k++) s -= L[k * m + i] * y[k];
+        y[i] = s / L[i * m + i];
+    }
+}
+
+typedef struct {
+    double **L, **M, **m; /* per stage: chol(Huu) nu*nu, L^{-1}Hux nu*nx, L^{-1}gu nu */
+} ricc_fact;
+
+/* Backward Riccati sweep.  factor != 0: build L,M from D (= R + diag(sig)) and the data;
+ * always: vector recursion with gradient rhat, offsets bb (NULL = 0), state gradient qq
+ * (NULL = 0), terminal qN (NULL = 0).  Returns 0 ok, 1 factorisation failure.           */
+static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int homogeneous,
+                            int factor, ricc_fact *f, double **Pb_store)
+{
+    const int N = p->N;
+    double P[NX * NX], pv[NX], PA[NX * NX], Hxx[NX * NX], h[NX], gx[NX];
+    (void)Pb_store;
+    if (factor) memcpy(P, p->QN, sizeof(P));
+    for (int i = 0; i < NX; i++) pv[i] = homogeneous ? 0.0 : p->qN[i];
+    /* In the factor pass P holds P_{k+1}.  In a vector-only pass (factor == 0) the
+     * homogeneous recursion needs no P at all (b = 0).                                   */
+    for (int k = N - 1; k >= 0; k--) {
+        const int m = p->nu[k];
+        const double *A = p->A[k], *B = p->B[k];
+        double *L = f->L[k], *M = f->M[k], *mv = f->m[k];
+        double *PB = dalloc((size_t)NX * m);
+        double *gu = dalloc(m);
+        /* h = P b + p */
+        for (int i = 0; i < NX; i++) {
+            double s = pv[i];
+            if (!homogeneous)
+                for (int j = 0; j < NX; j++) s += P[i * NX + j] * p->b[k][j];
+            h[i] = s;
+        }
+        if (factor) {
+            for (int i = 0; i < NX; i++) {
+                for (int j = 0; j < NX; j++) {
+                    double s = 0.0;
+                    for (int l = 0; l < NX; l++) s += P[i * NX + l] * A[l * NX + j];
+                    PA[i * NX + j] = s;
+                }
+                for (int j = 0; j < m; j++) {
+                    double s = 0.0;
+                    for (int l = 0; l < NX; l++) s += P[i * NX + l] * B[l * m + j];
+                    PB[i * m + j] = s;
+                }
+            }
+            /* Huu = R + diag(sig) + B' P B */
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j < m; j++) {
+                    double s = p->R[k][i * m + j] + (i == j ? sig[k][i] : 0.0);
+                    for (int l = 0; l < NX; l++) s += B[l * m + i] * PB[l * m + j];
+                    L[i * m + j] = s;
+                }
+            /* Hux = S + B' P A */
+            for (int i = 0; i < m; i++)
+                for (int j = 0; j < NX; j++) {
+                    double s = p->S[k][i * NX + j];
+                    for (int l = 0; l < NX; l++) s += B[l * m + i] * PA[l * NX + j];
+                    M[i * NX + j] = s;
+                }
+            /* Hxx = Q + A' P A */
+            for (int i = 0; i < NX; i++)
+                for (int j = 0; j < NX; j++) {
+                    double s = p->Q[k][i * NX + j];
+                    for (int l = 0; l < NX; l++) s += A[l * NX + i] * PA[l * NX + j];
+                    Hxx[i * NX + j] = s;
+                }
+            if (chol_lower(L, m)) { free(PB); free(gu); return 1; }
+            trsm_lower(L, m, M, NX);
+            /* P_k = Hxx - M'M, symmetrised */
+            for (int i = 0; i < NX; i++)
+                for (int j = 0; j < NX; j++) {
+                    double s = Hxx[i * NX + j];
+                    for (int l = 0; l < m; l++) s -= M[l * NX + i] * M[l * NX + j];
+                    PA[i * NX + j] = s;
+                }
+            for (int i = 0; i < NX; i++)
+                for (int j = 0; j < NX; j++) P[i * NX + j] = 0.5 * (PA[i * NX + j] + PA[j * NX + i]);
+        }
+        /* gu = rhat + B'h ; gx = q + A'h */
+        for (int i = 0; i < m; i++) {
+            double s = rhat[k][i];
+            for (int l = 0; l < NX; l++) s += B[l * m + i] * h[l];
+            gu[i] = s;
+        }
+        for (int i = 0; i < NX; i++) {
+            double s = homogeneous ? 0.0 : p->q[k][i];
+            for (int l = 0; l < NX; l++) s += A[l * NX + i] * h[l];
+            gx[i] = s;
+        }
+        trsm_lower(L, m, gu, 1);
+        memcpy(mv, gu, sizeof(double) * m);
+        for (int i = 0; i < NX; i++) {
+            double s = gx[i];
+            for (int l = 0; l < m; l++) s -= M[l * NX + i] * mv[l];
+            pv[i] = s;
+        }
+        free(PB);
+        free(gu);
+    }
+    return 0;
+}
+
+/* forward sweep: xh_0 = dx0 (or 0), uh_k = -L^{-T}(M xh_k + m), xh_{k+1} = A xh + B uh + b */
+static void riccati_forward(const ocpqp *p, const ricc_fact *f, const double *dx0,
+                            int homogeneous, double **uh, double *xh /*(N+1)*NX*/)
+{
+    const int N = p->N;
+    for (int i = 0; i < NX; i++) xh[i] = (homogeneous || !dx0) ? 0.0 : dx0[i];
+    for (int k = 0; k < N; k++) {
+        const int m = p->nu[k];
+        const double *xk = xh + k * NX;
+        double *xn = xh + (k + 1) * NX;
+        for (int i = 0; i < m; i++) {
+            double s = f->m[k][i];
+            for (int j = 0; j < NX; j++) s += f->M[k][i * NX + j] * xk[j];
+            uh[k][i] = -s;
+        }
+        trsv_lower_t(f->L[k], m, uh[k]);
+        for (int i = 0; i < NX; i++) {
+            double s = homogeneous ? 0.0 : p->b[k][i];
+            for (int j = 0; j < NX; j++) s += p->A[k][i * NX + j] * xk[j];
+            for (int j = 0; j < m; j++) s += p->B[k][i * m + j] * uh[k][j];
+            xn[i] = s;
+        }
+    }
+}
+
+/* [UPSTREAM] HPIPM-style Mehrotra predictor-corrector interior point method on the
+ * OCP-QP, Riccati factorisation of the KKT system, cold-started every call (U9).
+ * Feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
+ * states are implied by the (affine) dynamics, so the only residuals are stationarity
+ * (scales by 1-alpha per step; tracked as rho) and complementarity (mu).                */
+static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
+                     double **u /*out*/, double *x /*out (N+1)*NX*/, orc_stats *st)
+{
+    const int N = p->N;
+    int nc = 0, status = 0, it = 0;
+    ricc_fact f;
+    f.L = (double **)malloc(sizeof(double *) * N);
+    f.M = (double **)malloc(sizeof(double *) * N);
+    f.m = (double **)malloc(sizeof(double *) * N);
+    double **ll = (double **)malloc(sizeof(double *) * N), **lu = (double **)malloc(sizeof(double *) * N);
+    double **sig = (double **)malloc(sizeof(double *) * N), **rh = (double **)malloc(sizeof(double *) * N);
+    double **ua = (double **)malloc(sizeof(double *) * N), **du = (double **)malloc(sizeof(double *) * N);
+    double **dla = (double **)malloc(sizeof(double *) * N), **dua = (double **)malloc(sizeof(double *) * N);
+    double *xh = dalloc((size_t)(N + 1) * NX);
+    for (int k = 0; k < N; k++) {
+        const int m = p->nu[k];
+        nc += 2 * m;
+        f.L[k] = dalloc((size_t)m * m); f.M[k] = dalloc((size_t)m * NX); f.m[k] = dalloc(m);
+        ll[k] = dalloc(m); lu[k] = dalloc(m); sig[k] = dalloc(m); rh[k] = dalloc(m);
+        ua[k] = dalloc(m); du[k] = dalloc(m); dla[k] = dalloc(m); dua[k] = dalloc(m);
+        for (int i = 0; i < m; i++) {
+            const double lo = p->lo[k][i], hi = p->hi[k][i];
+            double thr = c->qp_thr0;
+            if (c->qp_thr0_rel * (hi - lo) > thr) thr = c->qp_thr0_rel * (hi - lo);
+            if (hi - lo < 2.0 * thr) thr = 0.5 * (hi - lo);
+            double v = 0.0;
+            if (v - lo < thr) v = lo + thr;
+            if (hi - v < thr) v = hi - thr;
+            u[k][i] = v;
+            ll[k][i] = c->qp_mu0 / (v - lo);
+            lu[k][i] = c->qp_mu0 / (hi - v);
+        }
+    }
+    double rho = 1.0, mu = 0.0;
+    const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
+    for (;;) {
+        mu = 0.0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++)
+                mu += ll[k][i] * (u[k][i] - p->lo[k][i]) + lu[k][i] * (p->hi[k][i] - u[k][i]);
+        mu /= nc;
+        if (!(mu == mu)) { status = 1; break; }
+        if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat) break;
+        if (it >= itmax) { status = 2; break; }
+        it++;
+        /* predictor (affine scaling) */
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                sig[k][i] = ll[k][i] / tl + lu[k][i] / tu;
+                rh[k][i] = p->r[k][i] - sig[k][i] * u[k][i];
+            }
+        if (riccati_backward(p, sig, rh, 0, 1, &f, NULL)) { status = 3; break; }
+        riccati_forward(p, &f, dx0, 0, ua, xh);
+        double aaff = 1.0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                const double d = ua[k][i] - u[k][i];
+                dla[k][i] = -ll[k][i] - ll[k][i] / tl * d;
+                dua[k][i] = -lu[k][i] + lu[k][i] / tu * d;
+                if (d < 0.0 && -tl / d < aaff) aaff = -tl / d;
+                if (d > 0.0 && tu / d < aaff) aaff = tu / d;
+                if (dla[k][i] < 0.0 && -ll[k][i] / dla[k][i] < aaff) aaff = -ll[k][i] / dla[k][i];
+                if (dua[k][i] < 0.0 && -lu[k][i] / dua[k][i] < aaff) aaff = -lu[k][i] / dua[k][i];
+            }
+        double muaff = 0.0;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                const double d = ua[k][i] - u[k][i];
+                muaff += (ll[k][i] + aaff * dla[k][i]) * (tl + aaff * d) +
+                         (lu[k][i] + aaff * dua[k][i]) * (tu - aaff * d);
+            }
+        muaff /= nc;
+        double sg = muaff / mu;
+        sg = sg * sg * sg;
+        /* corrector: homogeneous solve for the change of the input gradient */
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                const double d = ua[k][i] - u[k][i];
+                const double cl = dla[k][i] * d, cu = dua[k][i] * (-d);
+                rh[k][i] = -(sg * mu - cl) / tl + (sg * mu - cu) / tu;
+            }
+        riccati_backward(p, sig, rh, 1, 0, &f, NULL);
+        riccati_forward(p, &f, NULL, 1, du, xh);
+        double amax = 1e300;
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                const double da = ua[k][i] - u[k][i];
+                const double cl = dla[k][i] * da, cu = dua[k][i] * (-da);
+                const double d = da + du[k][i];
+                du[k][i] = d;
+                dla[k][i] = -(ll[k][i] * tl + cl - sg * mu) / tl - ll[k][i] / tl * d;
+                dua[k][i] = -(lu[k][i] * tu + cu - sg * mu) / tu + lu[k][i] / tu * d;
+                if (d < 0.0 && -tl / d < amax) amax = -tl / d;
+                if (d > 0.0 && tu / d < amax) amax = tu / d;
+                if (dla[k][i] < 0.0 && -ll[k][i] / dla[k][i] < amax) amax = -ll[k][i] / dla[k][i];
+                if (dua[k][i] < 0.0 && -lu[k][i] / dua[k][i] < amax) amax = -lu[k][i] / dua[k][i];
+            }
+        double alpha = c->qp_tau * amax;
+        if (alpha > 1.0) alpha = 1.0;
+        if (!(alpha == alpha)) { status = 1; break; }
+        /* centrality safeguard (wide neighbourhood N_-inf(gamma)): shorten the step until
+         * no complementarity product falls below gamma * (new mean).  Without it the
+         * plain Mehrotra heuristic can 2-cycle when one pair blocks the affine step.     */
+        if (c->qp_gamma > 0.0) {
+            for (int bt = 0; bt < 30; bt++) {
+                double mun = 0.0, pmin = 1e300;
+                for (int k = 0; k < N; k++)
+                    for (int i = 0; i < p->nu[k]; i++) {
+                        const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+                        const double p1 = (ll[k][i] + alpha * dla[k][i]) * (tl + alpha * du[k][i]);
+                        const double p2 = (lu[k][i] + alpha * dua[k][i]) * (tu - alpha * du[k][i]);
+                        mun += p1 + p2;
+                        if (p1 < pmin) pmin = p1;
+                        if (p2 < pmin) pmin = p2;
+                    }
+                mun /= nc;
+                if (pmin >= c->qp_gamma * mun) break;
+                alpha *= 0.75;
+            }
+        }
+        if (alpha < 1e-12) { status = 3; break; }
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                u[k][i] += alpha * du[k][i];
+                ll[k][i] += alpha * dla[k][i];
+                lu[k][i] += alpha * dua[k][i];
+            }
+        rho *= (1.0 - alpha);
+        if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d mu %.3e aaff %.3e muaff %.3e sg %.3e alpha %.3e rho %.3e\n", it, mu, aaff, muaff, sg, alpha, rho);
+    }
+    /* final rollout of the states from the inputs (dynamics are affine) */
+    for (int i = 0; i < NX; i++) x[i] = dx0 ? dx0[i] : 0.0;
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < NX; i++) {
+            double s = p->b[k][i];
+            for (int j = 0; j < NX; j++) s += p->A[k][i * NX + j] * x[k * NX + j];
+            for (int j = 0; j < p->nu[k]; j++) s += p->B[k][i * p->nu[k] + j] * u[k][j];
+            x[(k + 1) * NX + i] = s;
+        }
+    if (st) {
+        /* TRUE residuals, recomputed from scratch (diagnostics for the tests) */
+        double pi[NX], pin[NX], rs = 0.0, rc = 0.0;
+        for (int i = 0; i < NX; i++) {
+            double s = p->qN[i];
+            for (int j = 0; j < NX; j++) s += p->QN[i * NX + j] * x[N * NX + j];
+            pi[i] = s;
+        }
+        for (int k = N - 1; k >= 0; k--) {
+            const int m = p->nu[k];
+            for (int i = 0; i < m; i++) {
+                double s = p->r[k][i] - ll[k][i] + lu[k][i];
+                for (int j = 0; j < m; j++) s += p->R[k][i * m + j] * u[k][j];
+                for (int j = 0; j < NX; j++) s += p->S[k][i * NX + j] * x[k * NX + j];
+                for (int j = 0; j < NX; j++) s += p->B[k][j * m + i] * pi[j];
+                if (fabs(s) > rs) rs = fabs(s);
+                const double c1 = ll[k][i] * (u[k][i] - p->lo[k][i]);
+                const double c2 = lu[k][i] * (p->hi[k][i] - u[k][i]);
+                if (c1 > rc) rc = c1;
+                if (c2 > rc) rc = c2;
+            }
+            for (int i = 0; i < NX; i++) {
+                double s = p->q[k][i];
+                for (int j = 0; j < NX; j++) s += p->Q[k][i * NX + j] * x[k * NX + j];
+                for (int j = 0; j < m; j++) s += p->S[k][j * NX + i] * u[k][j];
+                for (int j = 0; j < NX; j++) s += p->A[k][j * NX + i] * pi[j];
+                pin[i] = s;
+            }
+            memcpy(pi, pin, sizeof(pi));
+        }
+        st->qp_iter = it; st->qp_status = status; st->res_stat = rs; st->res_eq = 0.0;
+        st->res_comp = rc; st->mu = mu; st->rho = rho;
+    }
+    for (int k = 0; k < N; k++) {
+        free(f.L[k]); free(f.M[k]); free(f.m[k]); free(ll[k]); free(lu[k]); free(sig[k]);
+        free(rh[k]); free(ua[k]); free(du[k]); free(dla[k]); free(dua[k]);
+    }
+    free(f.L); free(f.M); free(f.m); free(ll); free(lu); free(sig); free(rh); free(ua);
+    free(du); free(dla); free(dua); free(xh);
+    return status;
+}
+
+/* [UPSTREAM] HPIPM partial condensing block sizes: N stages into N2 blocks, remainder
+ * spread over the first blocks.                                                          */
+static void cond_block_sizes(int N, int N2, int *bs)
+{
+    const int base = N / N2, rem = N - N2 * base;
+    for (int i = 0; i < N2; i++) bs[i] = base + (i < rem ? 1 : 0);
+}
+
+int orc_qp_solve(const orc_config *c, const double *dx0,
+                 const double *A, const double *B, const double *b,
+                 const double *q, const double *r, const double *lo, const double *hi,
+                 const double *Qd, const double *Rd,
+                 double *dx, double *du, orc_stats *st)
+{
+    const int N = c->N;
+    int N2 = (c->qp_cond_N > 0 && c->qp_cond_N < N) ? c->qp_cond_N : N;
+    int *bs = (int *)malloc(sizeof(int) * (size_t)N2);
+    int *nu2 = (int *)malloc(sizeof(int) * (size_t)N2);
+    cond_block_sizes(N, N2, bs);
+    for (int i = 0; i < N2; i++) nu2[i] = NU * bs[i];
+    ocpqp p;
+    ocpqp_alloc(&p, N2, nu2);
+    /* per block: Phi_j (nx*nx), Gam_j (nx*nub), c_j (nx) for j = 0..bs (U8) */
+    int k0 = 0;
+    double **Phi_all = (double **)malloc(sizeof(double *) * N2);
+    double **Gam_all = (double **)malloc(sizeof(double *) * N2);
+    double **c_all = (double **)malloc(sizeof(double *) * N2);
+    for (int ib = 0; ib < N2; ib++) {
+        const int nb = bs[ib], m = nu2[ib];
+        double *Phi = dalloc((size_t)(nb + 1) * NX * NX);
+        double *Gam = dalloc((size_t)(nb + 1) * NX * m);
+        double *cc = dalloc((size_t)(nb + 1) * NX);
+        Phi_all[ib] = Phi; Gam_all[ib] = Gam; c_all[ib] = cc;
+        for (int i = 0; i < NX; i++) Phi[i * NX + i] = 1.0;
+        for (int j = 0; j < nb; j++) {
+            const double *Ak = A + (size_t)(k0 + j) * NX * NX, *Bk = B + (size_t)(k0 + j) * NX * NU;
+            const double *bk = b + (size_t)(k0 + j) * NX;
+            const double *Pj = Phi + (size_t)j * NX * NX, *Gj = Gam + (size_t)j * NX * m, *cj = cc + (size_t)j * NX;
+            double *Pn = Phi + (size_t)(j + 1) * NX * NX, *Gn = Gam + (size_t)(j + 1) * NX * m, *cn = cc + (size_t)(j + 1) * NX;
+            for (int i = 0; i < NX; i++) {
+                for (int l = 0; l < NX; l++) {
+                    double s = 0.0;
+                    for (int t = 0; t < NX; t++) s += Ak[i * NX + t] * Pj[t * NX + l];
+                    Pn[i * NX + l] = s;
+                }
+                for (int l = 0; l < m; l++) {
+                    double s = 0.0;
+                    for (int t = 0; t < NX; t++) s += Ak[i * NX + t] * Gj[t * m + l];
+                    Gn[i * m + l] = s;
+                }
+                for (int l = 0; l < NU; l++) Gn[i * m + j * NU + l] += Bk[i * NU + l];
+                double s = bk[i];
+                for (int t = 0; t < NX; t++) s += Ak[i * NX + t] * cj[t];
+                cn[i] = s;
+            }
+        }
+        memcpy(p.A[ib], Phi + (size_t)nb * NX * NX, sizeof(double) * NX * NX);
+        memcpy(p.B[ib], Gam + (size_t)nb * NX * m, sizeof(double) * NX * m);
+        memcpy(p.b[ib], cc + (size_t)nb * NX, sizeof(double) * NX);
+        for (int j = 0; j < nb; j++) {
+            const double *Pj = Phi + (size_t)j * NX * NX, *Gj = Gam + (size_t)j * NX * m, *cj = cc + (size_t)j * NX;
+            const double *Qk = Qd + (size_t)(k0 + j) * NX, *qk = q + (size_t)(k0 + j) * NX;
+            double w[NX];
+            for (int t = 0; t < NX; t++) w[t] = Qk[t] * cj[t] + qk[t];
+            for (int i = 0; i < NX; i++) {
+                for (int l = 0; l < NX; l++) {
+                    double s = 0.0;
+                    for (int t = 0; t < NX; t++) s += Pj[t * NX + i] * Qk[t] * Pj[t * NX + l];
+                    p.Q[ib][i * NX + l] += s;
+                }
+                double s = 0.0;
+                for (int t = 0; t < NX; t++) s += Pj[t * NX + i] * w[t];
+                p.q[ib][i] += s;
+            }
+            for (int i = 0; i < m; i++) {
+                for (int l = 0; l < NX; l++) {
+                    double s = 0.0;
+                    for (int t = 0; t < NX; t++) s += Gj[t * m + i] * Qk[t] * Pj[t * NX + l];
+                    p.S[ib][i * NX + l] += s;
+                }
+                for (int l = 0; l < m; l++) {
+                    double s = 0.0;
+                    for (int t = 0; t < NX; t++) s += Gj[t * m + i] * Qk[t] * Gj[t * m + l];
+                    p.R[ib][i * m + l] += s;
+                }
+                double s = 0.0;
+                for (int t = 0; t < NX; t++) s += Gj[t * m + i] * w[t];
+                p.r[ib][i] += s;
+            }
+            for (int l = 0; l < NU; l++) {
+                const int i = j * NU + l;
+                p.R[ib][i * m + i] += Rd[(size_t)(k0 + j) * NU + l];
+                p.r[ib][i] += r[(size_t)(k0 + j) * NU + l];
+                p.lo[ib][i] = lo[(size_t)(k0 + j) * NU + l];
+                p.hi[ib][i] = hi[(size_t)(k0 + j) * NU + l];
+            }
+        }
+        k0 += nb;
+    }
+    for (int i = 0; i < NX; i++) {
+        p.QN[i * NX + i] = Qd[(size_t)N * NX + i];
+        p.qN[i] = q[(size_t)N * NX + i];
+    }
+    double **u2 = (double **)malloc(sizeof(double *) * N2);
+    for (int ib = 0; ib < N2; ib++) u2[ib] = dalloc(nu2[ib]);
+    double *x2 = dalloc((size_t)(N2 + 1) * NX);
+    const int status = ocpqp_ipm(c, &p, dx0, u2, x2, st);
+    /* expansion back to the N-stage trajectory */
+    k0 = 0;
+    for (int ib = 0; ib < N2; ib++) {
+        const int nb = bs[ib], m = nu2[ib];
+        for (int j = 0; j < nb; j++) {
+            for (int l = 0; l < NU; l++) du[(size_t)(k0 + j) * NU + l] = u2[ib][j * NU + l];
+            const double *Pj = Phi_all[ib] + (size_t)j * NX * NX, *Gj = Gam_all[ib] + (size_t)j * NX * m;
+            const double *cj = c_all[ib] + (size_t)j * NX;
+            for (int i = 0; i < NX; i++) {
+                double s = cj[i];
+                for (int t = 0; t < NX; t++) s += Pj[i * NX + t] * x2[ib * NX + t];
+                for (int t = 0; t < m; t++) s += Gj[i * m + t] * u2[ib][t];
+                dx[(size_t)(k0 + j) * NX + i] = s;
+            }
+        }
+        k0 += nb;
+    }
+    memcpy(dx + (size_t)N * NX, x2 + (size_t)N2 * NX, sizeof(double) * NX);
+    for (int ib = 0; ib < N2; ib++) {
+        free(u2[ib]); free(Phi_all[ib]); free(Gam_all[ib]); free(c_all[ib]);
+    }
+    free(u2); free(x2); free(Phi_all); free(Gam_all); free(c_all); free(bs); free(nu2);
+    ocpqp_free(&p);
+    return status;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* [UPSTREAM] ocp_nlp_sqp_rti: preparation + feedback, full step (U1), status (U10).      */
+int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
+                const double *yref_e, double *xtraj, double *utraj, orc_stats *st)
+{
+    const int N = c->N;
+    double *A = dalloc((size_t)N * NX * NX), *B = dalloc((size_t)N * NX * NU), *b = dalloc((size_t)N * NX);
+    double *q = dalloc((size_t)(N + 1) * NX), *r = dalloc((size_t)N * NU);
+    double *lo = dalloc((size_t)N * NU), *hi = dalloc((size_t)N * NU);
+    double *Qd = dalloc((size_t)(N + 1) * NX), *Rd = dalloc((size_t)N * NU);
+    double *dx = dalloc((size_t)(N + 1) * NX), *du = dalloc((size_t)N * NU);
+    double dx0[NX];
+    int projected = 0, status = 0;
+    orc_stats local;
+    memset(&local, 0, sizeof(local));
+    orc_linearize(c, xtraj, utraj, yref, yref_e, A, B, b, q, r, lo, hi, Qd, Rd, &projected);
+    /* lbx_0 = ubx_0 = x0 (controller.py:414-415): delta x_0 is pinned to x0 - x_0 (U7) */
+    for (int i = 0; i < NX; i++) dx0[i] = x0[i] - xtraj[i];
+    const int qps = orc_qp_solve(c, dx0, A, B, b, q, r, lo, hi, Qd, Rd, dx, du, &local);
+    local.hess_projected = projected;
+    int bad = 0;
+    for (int i = 0; i < (N + 1) * NX; i++) if (!(dx[i] == dx[i]) || fabs(dx[i]) > 1e300) bad = 1;
+    for (int i = 0; i < N * NU; i++) if (!(du[i] == du[i]) || fabs(du[i]) > 1e300) bad = 1;
+    if (bad || qps == 1) status = 1;           /* ACADOS_NAN_DETECTED */
+    else if (qps == 3) status = 4;             /* QP min step / factorisation -> QP_FAILURE */
+    else status = 0;                           /* QP max-iter is tolerated in RTI (U10) */
+    if (status == 0) {
+        for (int i = 0; i < (N + 1) * NX; i++) xtraj[i] += dx[i];
+        for (int i = 0; i < N * NU; i++) utraj[i] += du[i];
+    }
+    if (st) *st = local;
+    free(A); free(B); free(b); free(q); free(r); free(lo); free(hi); free(Qd); free(Rd);
+    free(dx); free(du);
+    return status;
+}
+
+int orc_solve_batch(const orc_config *c, int Bn, const double *x0, const double *yref,
+                    const double *yref_e, int yref_bcast,
+                    const double *x_init, const double *u_init,
+                    double *u0, int *status, double *x_out, double *u_out,
+                    int *iters, int nthreads)
+{
+    const int N = c->N;
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#else
+    (void)nthreads;
+#endif
+#pragma omp parallel for schedule(dynamic, 16)
+    for (int ib = 0; ib < Bn; ib++) {
+        double *xt = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
+        double *ut = (double *)malloc(sizeof(double) * (size_t)N * NU);
+        const double *x0i = x0 + (size_t)ib * NX;
+        if (x_init && u_init) {
+            memcpy(xt, x_init + (size_t)ib * (N + 1) * NX, sizeof(double) * (size_t)(N + 1) * NX);
+            memcpy(ut, u_init + (size_t)ib * N * NU, sizeof(double) * (size_t)N * NU);
+            memcpy(xt, x0i, sizeof(double) * NX); /* controller.py:416 */
+        } else {
+            for (int k = 0; k <= N; k++) memcpy(xt + (size_t)k * NX, x0i, sizeof(double) * NX);
+            memset(ut, 0, sizeof(double) * (size_t)N * NU);
+        }
+        const double *yr = yref_bcast ? yref : yref + (size_t)ib * N * NY;
+        const double *ye = yref_bcast ? yref_e : yref_e + (size_t)ib * NX;
+        orc_stats st;
+        const int s = orc_sqp_rti(c, x0i, yr, ye, xt, ut, &st);
+        if (status) status[ib] = s;
+        if (iters) iters[ib] = st.qp_iter;
+        for (int i = 0; i < NU; i++) u0[(size_t)ib * NU + i] = (s == 0) ? ut[i] : 0.0; /* controller.py:448-450 */
+        if (x_out) memcpy(x_out + (size_t)ib * (N + 1) * NX, xt, sizeof(double) * (size_t)(N + 1) * NX);
+        if (u_out) memcpy(u_out + (size_t)ib * N * NU, ut, sizeof(double) * (size_t)N * NU);
+        free(xt);
+        free(ut);
+    }
+    return 0;
+}
