@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: batched cold-start SQP-RTI solves on MI355X.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it is launched by
+torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
+
+A "step" = one batch of B independent NMPC instances solved start to finish (linearise ->
+interior-point QP -> full SQP step) with the inputs already resident in HBM, followed - when
+N>1 - by the RCCL all-gather of the first-stage commands u0 (the only exchange the path has).
+Workload = BASELINE.json configs[1]: B = 4096 near-hover initial states per GPU, horizon 20,
+FP64, hover reference materialised per instance ([B,N,17]).
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBS = 8000.0        # /opt/skills/guides/MI355X_MICROARCH.md, chip-level parameters
+FP64_VEC_PEAK_TF = 78.6      # 256 CU x 4 SIMD x 16 lanes x 2 flop x 2.4 GHz
+FP32_VEC_PEAK_TF = 157.3
+
+
+def algorithmic_bytes(N: int, esz: int, bcast: bool, traj_out: bool) -> int:
+    """compulsory I/O of one solve."""
+    n_in = 13 + (0 if bcast else N * 17 + 13)
+    b = n_in * esz + 4 * esz + 4
+    if traj_out:
+        b += ((N + 1) * 13 + N * 4) * esz
+    return b
+
+
+def algorithmic_flops(N: int, n_ipm: float) -> float:
+    """F = N*F_lin + n_ipm*N*F_kkt (dense-equivalent count, nominal)."""
+    return N * 7.7e3 + n_ipm * N * 11.9e3
+
+
+def cpu_baseline(B_sample: int, N: int):
+    """The CPU oracle (a port, not acados) on this box's host cores, bounded sample."""
+    from oracle import oracle as O
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, sample_x0
+    c = O.default_config(N=N, qp_gamma=0.0)
+    yref, ye = O.hover_yref(c)
+    x0 = sample_x0(B_sample, 0, **NEAR_HOVER)
+    cores = len(os.sched_getaffinity(0))
+    O.solve_batch(c, x0[:64], yref, ye, nthreads=cores)       # warm the pool
+    t = time.perf_counter()
+    out = O.solve_batch(c, x0, yref, ye, nthreads=cores)
+    dt_all = time.perf_counter() - t
+    n1 = max(64, B_sample // max(cores, 1))
+    t = time.perf_counter()
+    O.solve_batch(c, x0[:n1], yref, ye, nthreads=1)
+    dt_1 = time.perf_counter() - t
+    return out, dict(value=B_sample / dt_all, unit="solves/s", cores=cores, kind="port",
+                     sample=f"{B_sample} of the config-2 instances (seed 0), OpenMP over instances, "
+                            f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM)",
+                     single_thread_value=n1 / dt_1)
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
+    ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--dist", choices=["near_hover", "aggressive"], default="near_hover")
+    ap.add_argument("--yref", choices=["per_instance", "broadcast"], default="per_instance")
+    ap.add_argument("--no-share", action="store_true", help="do not exploit the shared cold-start linearisation")
+    ap.add_argument("--traj-out", action="store_true", help="also write the full x/u trajectories")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=4096)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from rotors_mpc_controller_amd import _lib
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    B, N = args.batch, args.horizon
+    tdt, npdt, esz = (torch.float64, np.float64, 8) if args.dtype == "f64" else (torch.float32, np.float32, 4)
+    cfg = _lib.default_config(N=N, max_batch=B, device=local,
+                              dtype=_lib.DTYPE_F64 if args.dtype == "f64" else _lib.DTYPE_F32,
+                              flags=0 if args.no_share else _lib.FLAG_SHARE_COLD_START)
+    if args.dtype == "f32":
+        cfg.update(qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+    solver = NmpcOcpSolver(cfg)
+    hover = cfg.mass * cfg.gravity / 4.0
+    seed = 0 if world == 1 else 100 + rank                      # config 2 / config 4
+    dist_kw = NEAR_HOVER if args.dist == "near_hover" else AGGRESSIVE
+    x0_h = sample_x0(B, seed, **dist_kw)
+    yref_h, yref_e_h = hover_reference(N, hover)
+    bcast = args.yref == "broadcast"
+    x0 = torch.from_numpy(x0_h.astype(npdt)).to(dev)
+    if bcast:
+        yref = torch.from_numpy(yref_h.astype(npdt)).to(dev)
+        yref_e = torch.from_numpy(yref_e_h.astype(npdt)).to(dev)
+    else:
+        yref = torch.from_numpy(np.tile(yref_h, (B, 1, 1)).astype(npdt)).to(dev).contiguous()
+        yref_e = torch.from_numpy(np.tile(yref_e_h, (B, 1)).astype(npdt)).to(dev).contiguous()
+    u0 = torch.zeros(B, 4, dtype=tdt, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    xo = torch.zeros(B, N + 1, 13, dtype=tdt, device=dev) if args.traj_out else None
+    uo = torch.zeros(B, N, 4, dtype=tdt, device=dev) if args.traj_out else None
+    gathered = torch.zeros(world * B, 4, dtype=tdt, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream(dev)
+
+    def step():
+        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0.data_ptr(),
+                                  status_ptr=status.data_ptr(),
+                                  x_out_ptr=xo.data_ptr() if xo is not None else 0,
+                                  u_out_ptr=uo.data_ptr() if uo is not None else 0,
+                                  stream=stream.cuda_stream)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, u0)           # RCCL over xGMI
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0 = time.perf_counter()
+    ev0.record(stream)
+    for _ in range(args.steps):
+        step()
+    ev1.record(stream)
+    fence()
+    elapsed = time.perf_counter() - t0
+    dev_ms = ev0.elapsed_time(ev1) / args.steps
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = solver.stats()                                          # HIP events of the LAST timed step
+    u0_h = u0.cpu().numpy().astype(np.float64)
+    status_h = status.cpu().numpy()
+
+    if rank == 0:
+        ms_step = 1e3 * elapsed / args.steps
+        rate = world * B / (elapsed / args.steps)
+        n_ipm = st["iter_mean"]
+        kern_s = st["ms_solve"] * 1e-3
+        alg_b = algorithmic_bytes(N, esz, bcast, args.traj_out)
+        flops = algorithmic_flops(N, n_ipm)
+        f_peak = FP64_VEC_PEAK_TF if args.dtype == "f64" else FP32_VEC_PEAK_TF
+        hbm_alg_gbs = alg_b * B / kern_s / 1e9
+        alu_tf = flops * B / kern_s / 1e12
+        # streamed solver workspace per solve (kernel table): rows read+written per stage and IPM iteration
+        ws_rows = 820 if args.no_share else 420
+        ws_gbs = (n_ipm * N * ws_rows * esz) * B / kern_s / 1e9
+        roof = dict(bound="hbm", kernel="k_ipm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=hbm_alg_gbs / HBM_PEAK_GBS, traffic=None,
+                    kernel_ms=st["ms_solve"], prepare_ms=st["ms_prepare"], algorithmic_bytes_per_solve=alg_b,
+                    workspace_model_gbs=ws_gbs,
+                    alu=dict(achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak,
+                             flops_per_solve=flops, n_ipm_mean=n_ipm))
+        line = dict(metric="NMPC SQP-RTI solves/sec (N=20, nx=13, nu=4) at batch=4096 per GPU",
+                    value=rate, unit="solves/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
+                    ms_per_step=ms_step, device_ms_per_step=dev_ms, higher_is_better=True, scaling="weak",
+                    vs_baseline=None, dtype=args.dtype, data="synthetic",
+                    config=dict(workload=f"batch={B} random x0 around hover ({args.dist}, seed {seed}), N={N}, "
+                                         f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
+                                batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share,
+                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather u0"),
+                    ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
+                    status_histogram=st["n_status"], roofline=roof)
+        if world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and args.dist == "near_hover":
+            ns = min(args.cpu_sample, B)
+            ref, cb = cpu_baseline(ns, N)
+            line["cpu_baseline"] = cb
+            ok = (status_h[:ns] == 0) & (ref["status"] == 0)
+            line["max_abs_u0_vs_oracle"] = float(np.abs(u0_h[:ns][ok] - ref["u0"][ok]).max())
+            line["parity_note"] = "vs build CPU oracle; acados parity unpinned (SURVEY 8c)"
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

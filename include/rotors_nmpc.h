@@ -1,0 +1,152 @@
+/*
+ * rotors_nmpc.h -- C ABI of the MI355X-native batched NMPC solver (librotors_nmpc_hip.so).
+ *
+ * Drop-in boundary: the object the reference binds at
+ *   /root/reference/src/rotors_mpc_controller/controller.py:263   AcadosOcpSolver(ocp, json_file=...)
+ * and drives at controller.py:412-460 through set()/solve()/get().  acados_template itself is
+ * "Python -> ctypes -> C ABI of a generated shared object"; this header is the C ABI a
+ * maintainer would bind instead (see INTEGRATION.md for the ctypes stub).
+ *
+ * Plain C: pointers and sizes only, no torch / HIP types in any signature (a stream is
+ * passed as void*).  Every entry point names the reference call it replaces.
+ *
+ * Threading: one handle = one thread at a time (the reference serialises solve and rebuild
+ * with _controller_lock, nodes/mpc_controller_node:122,193).  All calls are synchronous at
+ * the ABI except nmpc_solve_batch_device, which only enqueues on the given stream.
+ */
+#ifndef ROTORS_NMPC_H
+#define ROTORS_NMPC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NMPC_NX 13 /* controller.py:157 */
+#define NMPC_NU 4  /* controller.py:158 */
+#define NMPC_NY 17 /* controller.py:159 */
+
+/* acados status numbering, consumed at controller.py:448 and mpc_controller_node:124 */
+#define NMPC_SUCCESS 0
+#define NMPC_NAN_DETECTED 1
+#define NMPC_MAXITER 2
+#define NMPC_MINSTEP 3
+#define NMPC_QP_FAILURE 4
+
+/* argument errors of set/get/solve_batch are negative and leave a message in nmpc_last_error */
+#define NMPC_EARG (-1)
+#define NMPC_EHIP (-2)
+
+#define NMPC_DTYPE_F64 0
+#define NMPC_DTYPE_F32 1
+
+/* flags */
+#define NMPC_FLAG_SHARE_COLD_START 1u /* cold start: all stages share one (A,B,b); linearise once */
+
+/* Everything controller.py:175-264 hands to AcadosOcp, plus the physical constants that the
+ * reference bakes into the CasADi expression (controller.py:311-341), as plain numbers.   */
+typedef struct nmpc_config {
+    int32_t N;                 /* ocp.dims.N                         controller.py:179 */
+    double dt;                 /* tf = N*dt                          controller.py:180 */
+    double W[NMPC_NY];         /* diag(ocp.cost.W)                   controller.py:237-242 */
+    double W_e[NMPC_NX];       /* diag(ocp.cost.W_e)                 controller.py:243 */
+    double lbu[NMPC_NU];       /* ocp.constraints.lbu                controller.py:249 */
+    double ubu[NMPC_NU];       /* ocp.constraints.ubu                controller.py:250 */
+    double levenberg_marquardt;/* solver_options.levenberg_marquardt controller.py:190 */
+    int32_t lm_scaled_by_dt;   /* [UPSTREAM U5] 1: stages use dt*lm (newer acados), 0: lm */
+    int32_t cost_scaled_by_dt; /* [UPSTREAM U4] 1: stage cost times dt, terminal not */
+    double mass;               /* controller.py:73  */
+    double gravity;            /* controller.py:74  */
+    double inertia[3];         /* diagonal only is used, controller.py:81-83 */
+    double rotor_x[NMPC_NU];   /* controller.py:100 */
+    double rotor_y[NMPC_NU];   /* controller.py:101 */
+    double rotor_z[NMPC_NU];   /* spin*k_m, controller.py:103 */
+    int32_t sim_num_stages;    /* must be 2 (explicit midpoint)      controller.py:187 */
+    int32_t sim_num_steps;     /* controller.py:188 */
+    int32_t qp_iter_max;       /* qp_solver_iter_max                 controller.py:185 */
+    int32_t qp_cond_N;         /* qp_solver_cond_N                   controller.py:184 (solution-invariant, U8) */
+    double qp_tol_comp;        /* IPM: stop when mu <= tol_comp and ... */
+    double qp_tol_stat;        /* ... relative stationarity factor <= tol_stat */
+    double qp_mu0;             /* initial barrier parameter */
+    double qp_tau;             /* fraction to the boundary */
+    double qp_thr0;            /* initial distance from the bounds, absolute ... */
+    double qp_thr0_rel;        /* ... and relative to the box width (the larger applies) */
+    int32_t dtype;             /* NMPC_DTYPE_F64 | NMPC_DTYPE_F32: arithmetic AND device buffers */
+    int32_t device;            /* HIP device ordinal */
+    int32_t max_batch;         /* workspace is sized for this many instances */
+    uint32_t flags;            /* NMPC_FLAG_* */
+} nmpc_config;
+
+typedef struct nmpc_stats {
+    int32_t batch;             /* instances in the last solve */
+    int32_t iter_min, iter_max;/* IPM iterations over the batch */
+    double iter_mean;
+    int32_t n_status[5];       /* histogram of the acados status codes */
+    double ms_prepare;         /* device time of the linearisation kernel (HIP events) */
+    double ms_solve;           /* device time of the IPM kernel */
+    uint64_t workspace_bytes;
+} nmpc_stats;
+
+typedef struct nmpc_solver nmpc_solver; /* opaque; owns all device memory */
+
+/* values of reference config/params.yaml + the acados defaults the reference relies on */
+void nmpc_default_config(nmpc_config *cfg);
+
+/* replaces AcadosOcpSolver(ocp, json_file=...)  controller.py:263 -- no codegen, no compile,
+ * no on-disk artefacts.  NULL on failure (message via nmpc_last_error(NULL)).              */
+nmpc_solver *nmpc_create(const nmpc_config *cfg);
+
+/* replaces `del old_solver` + rmtree of the codegen dir  controller.py:169-172 */
+void nmpc_destroy(nmpc_solver *s);
+
+/* replaces AcadosOcpSolver.set(stage, field, value)  controller.py:414-445.
+ * fields: "x" (n=13, stage 0..N), "u" (n=4, 0..N-1), "yref" (n=17 for stage<N, 13 at N),
+ * "lbx"/"ubx" (n=13, stage 0 only: the initial-state pin).  Single-instance slot.        */
+int nmpc_set(nmpc_solver *s, int stage, const char *field, const double *value, int n);
+
+/* replaces AcadosOcpSolver.get(stage, field)  controller.py:452-460; fields "x", "u" */
+int nmpc_get(nmpc_solver *s, int stage, const char *field, double *out, int n);
+
+/* replaces AcadosOcpSolver.solve()  controller.py:447: one SQP real-time iteration on the
+ * single-instance slot, run on the GPU (batch of one).  Returns the acados status.         */
+int nmpc_solve(nmpc_solver *s);
+
+/* Batched RTI, host buffers (copied in and out; PCIe inclusive).  All arrays are row-major
+ * doubles regardless of cfg.dtype.
+ *   x0      [B][13]
+ *   yref    [B][N][17] or, if yref_bcast, [N][17] shared by all instances
+ *   yref_e  [B][13]    or [13]
+ *   x_init  [B][N+1][13], u_init [B][N][4]: linearisation point (warm start,
+ *           controller.py:419-424); both NULL = cold start x_k = x0, u_k = 0 (:425-431)
+ *   u0      [B][4] out (zeros where status != 0, controller.py:448-450), status [B] out
+ *   x_out   [B][N+1][13], u_out [B][N][4] out, nullable
+ * Returns 0 or a negative argument/HIP error.                                             */
+int nmpc_solve_batch(nmpc_solver *s, int B, const double *x0, const double *yref,
+                     const double *yref_e, int yref_bcast, const double *x_init,
+                     const double *u_init, double *u0, int32_t *status, double *x_out,
+                     double *u_out);
+
+/* Same, all pointers are DEVICE pointers of element type cfg.dtype (double or float) and
+ * the work is only enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = default).
+ * status is int32 on the device.  This is the entry the benchmark times.                   */
+int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *yref,
+                            const void *yref_e, int yref_bcast, const void *x_init,
+                            const void *u_init, void *u0, int32_t *status, void *x_out,
+                            void *u_out, void *hip_stream);
+
+/* device-side IPM iteration counts of the last solve: int32 [B] DEVICE pointer (read-only) */
+const int32_t *nmpc_device_iterations(nmpc_solver *s);
+
+/* synchronises, then fills iteration / status histograms and kernel times of the last solve */
+int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out);
+
+/* message of the last failing call on this handle (s == NULL: of the last failed create) */
+const char *nmpc_last_error(const nmpc_solver *s);
+
+const char *nmpc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ROTORS_NMPC_H */

@@ -61,7 +61,7 @@ void orc_default_config(orc_config *c)
     c->qp_tau = 0.995;
     c->qp_thr0 = 0.1;
     c->qp_thr0_rel = 0.25;
-    c->qp_gamma = 1e-3;
+    c->qp_gamma = 0.0;   /* optional safeguard; the HIP kernels do not implement it */
 }
 
 /* ------------------------------------------------------------------------------------ */

@@ -1,0 +1,137 @@
+"""ctypes binding of include/rotors_nmpc.h (librotors_nmpc_hip.so).
+
+The library is the product: there is no Python or CPU fallback.  `load()` raises if the
+shared object is missing, and `nmpc_create` itself fails when no HIP device is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+from pathlib import Path
+
+NX, NU, NY = 13, 4, 17
+
+DTYPE_F64, DTYPE_F32 = 0, 1
+FLAG_SHARE_COLD_START = 1
+
+STATUS_NAMES = {0: "SUCCESS", 1: "NAN_DETECTED", 2: "MAXITER", 3: "MINSTEP", 4: "QP_FAILURE"}
+
+_PKG = Path(__file__).resolve().parent
+LIB_PATH = _PKG / "librotors_nmpc_hip.so"
+CSRC = _PKG / "csrc"
+
+
+class NmpcConfig(C.Structure):
+    """Mirror of `nmpc_config` (include/rotors_nmpc.h)."""
+    _fields_ = [
+        ("N", C.c_int32), ("dt", C.c_double),
+        ("W", C.c_double * NY), ("W_e", C.c_double * NX),
+        ("lbu", C.c_double * NU), ("ubu", C.c_double * NU),
+        ("levenberg_marquardt", C.c_double),
+        ("lm_scaled_by_dt", C.c_int32), ("cost_scaled_by_dt", C.c_int32),
+        ("mass", C.c_double), ("gravity", C.c_double), ("inertia", C.c_double * 3),
+        ("rotor_x", C.c_double * NU), ("rotor_y", C.c_double * NU), ("rotor_z", C.c_double * NU),
+        ("sim_num_stages", C.c_int32), ("sim_num_steps", C.c_int32),
+        ("qp_iter_max", C.c_int32), ("qp_cond_N", C.c_int32),
+        ("qp_tol_comp", C.c_double), ("qp_tol_stat", C.c_double), ("qp_mu0", C.c_double),
+        ("qp_tau", C.c_double), ("qp_thr0", C.c_double), ("qp_thr0_rel", C.c_double),
+        ("dtype", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_uint32),
+    ]
+
+    def update(self, **over) -> "NmpcConfig":
+        for k, v in over.items():
+            cur = getattr(self, k)
+            if hasattr(cur, "__len__"):
+                vals = list(v)
+                if len(vals) != len(cur):
+                    raise ValueError(f"{k} takes {len(cur)} values, got {len(vals)}")
+                for i, x in enumerate(vals):
+                    cur[i] = float(x)
+            else:
+                setattr(self, k, v)
+        return self
+
+
+class NmpcStats(C.Structure):
+    _fields_ = [
+        ("batch", C.c_int32), ("iter_min", C.c_int32), ("iter_max", C.c_int32),
+        ("iter_mean", C.c_double), ("n_status", C.c_int32 * 5),
+        ("ms_prepare", C.c_double), ("ms_solve", C.c_double), ("workspace_bytes", C.c_uint64),
+    ]
+
+
+EXPORTS = (
+    "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
+    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_get_stats",
+    "nmpc_last_error", "nmpc_version",
+)
+
+
+def build(force: bool = False) -> Path:
+    """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_consts.hpp")]
+    srcs.append(_PKG.parent / "include" / "rotors_nmpc.h")
+    stale = (not LIB_PATH.exists()) or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", str(CSRC)] + (["-B"] if force else []))
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """Load the HIP library.  Never falls back: a missing library is an error."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.
+    # If this library were loaded first it would pull in /opt/rocm's copies, and a later
+    # `import torch` would bring a second runtime whose device discovery then fails
+    # (observed on the GPU box: hipGetDeviceCount -> no device).  Importing torch first makes
+    # the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to torch's already-loaded one.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    path = Path(os.environ.get("ROTORS_NMPC_LIB", LIB_PATH))
+    if not path.exists():
+        raise RuntimeError(
+            f"{path} not found: build it with `make -C {CSRC}` (or __graft_entry__.build()). "
+            "rotors_mpc_controller_amd has no CPU fallback.")
+    lib = C.CDLL(str(path))
+    vp, dp, ip = C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int32)
+    cp = C.POINTER(NmpcConfig)
+    lib.nmpc_default_config.argtypes = [cp]
+    lib.nmpc_default_config.restype = None
+    lib.nmpc_create.argtypes = [cp]
+    lib.nmpc_create.restype = vp
+    lib.nmpc_destroy.argtypes = [vp]
+    lib.nmpc_destroy.restype = None
+    lib.nmpc_set.argtypes = [vp, C.c_int, C.c_char_p, dp, C.c_int]
+    lib.nmpc_set.restype = C.c_int
+    lib.nmpc_get.argtypes = [vp, C.c_int, C.c_char_p, dp, C.c_int]
+    lib.nmpc_get.restype = C.c_int
+    lib.nmpc_solve.argtypes = [vp]
+    lib.nmpc_solve.restype = C.c_int
+    lib.nmpc_solve_batch.argtypes = [vp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, dp, dp]
+    lib.nmpc_solve_batch.restype = C.c_int
+    lib.nmpc_solve_batch_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]
+    lib.nmpc_solve_batch_device.restype = C.c_int
+    lib.nmpc_device_iterations.argtypes = [vp]
+    lib.nmpc_device_iterations.restype = vp
+    lib.nmpc_get_stats.argtypes = [vp, C.POINTER(NmpcStats)]
+    lib.nmpc_get_stats.restype = C.c_int
+    lib.nmpc_last_error.argtypes = [vp]
+    lib.nmpc_last_error.restype = C.c_char_p
+    lib.nmpc_version.argtypes = []
+    lib.nmpc_version.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def default_config(**over) -> NmpcConfig:
+    cfg = NmpcConfig()
+    load().nmpc_default_config(C.byref(cfg))
+    return cfg.update(**over)

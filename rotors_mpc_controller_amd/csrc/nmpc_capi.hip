@@ -1,0 +1,453 @@
+// nmpc_capi.hip -- HIP kernels (gfx950) and the C ABI of include/rotors_nmpc.h.
+//
+// One MPC instance per wavefront lane; one 64-lane wave per workgroup so that a batch of B
+// instances becomes ceil(B/64) independent workgroups that the dispatcher spreads over all
+// XCDs.  No inter-workgroup communication exists on this path (instances are independent),
+// so no release/acquire protocol is needed.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/rotors_nmpc.h"
+#include "nmpc_ipm.hpp"
+#include "nmpc_consts.hpp"
+
+using namespace nmpc;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+template <class T>
+__global__ __launch_bounds__(64) void k_prepare(Consts<T> c, Work<T> w, Inputs<T> in, int B)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane < B) lane_prepare(c, w, in, lane);
+}
+
+template <class T>
+__global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Outputs<T> out, int B)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane < B) lane_ipm(c, w, out, lane);
+}
+
+}  // namespace
+
+struct nmpc_solver {
+    nmpc_config cfg;
+    std::string err;
+    int Bp = 0;
+    size_t esz = 8;
+    // device workspace (element type = cfg.dtype)
+    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr;
+    int32_t *d_iters = nullptr, *d_status = nullptr;
+    long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
+    // device staging for the host-pointer entry points
+    void *s_x0 = nullptr, *s_yref = nullptr, *s_yref_e = nullptr, *s_xi = nullptr, *s_ui = nullptr;
+    void *s_u0 = nullptr, *s_xo = nullptr, *s_uo = nullptr;
+    size_t staged_batch = 0;
+    uint64_t ws_bytes = 0;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    int last_B = 0;
+    bool timed = false;
+    // single-instance slot (AcadosOcpSolver.set/get state)
+    std::vector<double> sx, su, syref, syref_e, sx0;
+    bool x0_set = false;
+
+    int fail(int code, const char *fmt, ...)
+    {
+        char buf[512];
+        va_list ap;
+        va_start(ap, fmt);
+        vsnprintf(buf, sizeof(buf), fmt, ap);
+        va_end(ap);
+        err = buf;
+        return code;
+    }
+};
+
+#define HIP_TRY(s, call)                                                                      \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess) return (s)->fail(NMPC_EHIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+extern "C" {
+
+const char *nmpc_version(void) { return "rotors_nmpc_hip 0.1 (gfx950)"; }
+
+void nmpc_default_config(nmpc_config *c)
+{
+    // reference config/params.yaml:1-33 and controller.py:98-110
+    static const double W[NMPC_NY] = {10, 10, 8, 1, 1, 0.2, 3.2, 3.2, 3.2, 3.2, 1.4, 1.4, 0.4, 1.75, 1.75, 1.75, 1.75};
+    static const double We[NMPC_NX] = {5, 5, 3, 2, 2, 2, 12, 12, 12, 18.5, 2, 2, 1.8};
+    const double L = 0.17, kf = 8.54858e-6, km = 0.016;
+    const double spin[4] = {-1, 1, -1, 1}, rx[4] = {L, 0, -L, 0}, ry[4] = {0, L, 0, -L};
+    std::memset(c, 0, sizeof(*c));
+    c->N = 20;
+    c->dt = 0.05;
+    std::memcpy(c->W, W, sizeof(W));
+    std::memcpy(c->W_e, We, sizeof(We));
+    for (int i = 0; i < 4; i++) {
+        c->lbu[i] = kf * 50.0 * 50.0;
+        c->ubu[i] = kf * 838.0 * 838.0;
+        c->rotor_x[i] = rx[i];
+        c->rotor_y[i] = ry[i];
+        c->rotor_z[i] = spin[i] * km;
+    }
+    c->levenberg_marquardt = 7.0e-3;
+    c->lm_scaled_by_dt = 1;
+    c->cost_scaled_by_dt = 1;
+    c->mass = 0.68;
+    c->gravity = 9.81;
+    c->inertia[0] = 0.007; c->inertia[1] = 0.007; c->inertia[2] = 0.012;
+    c->sim_num_stages = 2;
+    c->sim_num_steps = 2;
+    c->qp_iter_max = 600;
+    c->qp_cond_N = 5;
+    c->qp_tol_comp = 1e-11;
+    c->qp_tol_stat = 1e-11;
+    c->qp_mu0 = 0.1;
+    c->qp_tau = 0.995;
+    c->qp_thr0 = 0.1;
+    c->qp_thr0_rel = 0.25;
+    c->dtype = NMPC_DTYPE_F64;
+    c->device = 0;
+    c->max_batch = 4096;
+    c->flags = NMPC_FLAG_SHARE_COLD_START;
+}
+
+static int alloc_ws(nmpc_solver *s)
+{
+    const size_t N = (size_t)s->cfg.N, Bp = (size_t)s->Bp, e = s->esz;
+    struct { void **p; size_t n; } a[] = {
+        {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
+        {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * LM_ROWS * Bp * e},
+        {&s->iv, N * IV_ROWS * Bp * e}, {(void **)&s->d_iters, Bp * sizeof(int32_t)},
+        {(void **)&s->d_status, Bp * sizeof(int32_t)}};
+    for (auto &x : a) {
+        HIP_TRY(s, hipMalloc(x.p, x.n));
+        s->ws_bytes += x.n;
+    }
+    return 0;
+}
+
+nmpc_solver *nmpc_create(const nmpc_config *cfg)
+{
+    auto bad = [](const char *m) { g_create_error = m; return (nmpc_solver *)nullptr; };
+    if (!cfg) return bad("nmpc_create: cfg is NULL");
+    if (cfg->N < 1 || cfg->N > 4096) return bad("nmpc_create: N out of range [1,4096]");
+    if (!(cfg->dt > 0)) return bad("nmpc_create: dt must be positive");
+    if (cfg->sim_num_stages != 2)
+        return bad("nmpc_create: only sim_method_num_stages = 2 (explicit midpoint, controller.py:187) is built");
+    if (cfg->sim_num_steps < 1) return bad("nmpc_create: sim_num_steps must be >= 1");
+    if (cfg->dtype != NMPC_DTYPE_F64 && cfg->dtype != NMPC_DTYPE_F32) return bad("nmpc_create: bad dtype");
+    if (cfg->max_batch < 1) return bad("nmpc_create: max_batch must be >= 1");
+    if (!(cfg->mass > 0) || !(cfg->inertia[0] > 0) || !(cfg->inertia[1] > 0) || !(cfg->inertia[2] > 0))
+        return bad("nmpc_create: mass and inertia must be positive");
+    for (int i = 0; i < NMPC_NU; i++)
+        if (!(cfg->ubu[i] > cfg->lbu[i])) return bad("nmpc_create: need lbu < ubu");
+    // PROJECT_REDUC_HESS (controller.py:189) as a check, not a transformation (U6)
+    const double sc = cfg->cost_scaled_by_dt ? cfg->dt : 1.0;
+    const double lmk = cfg->levenberg_marquardt * (cfg->lm_scaled_by_dt ? cfg->dt : 1.0);
+    for (int i = 0; i < NMPC_NY; i++)
+        if (!(sc * cfg->W[i] + lmk > 0)) return bad("nmpc_create: stage Hessian not positive definite (would need projection)");
+    for (int i = 0; i < NMPC_NX; i++)
+        if (!(cfg->W_e[i] + cfg->levenberg_marquardt > 0)) return bad("nmpc_create: terminal Hessian not positive definite");
+    int ndev = 0;
+    const hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev < 1) {
+        g_create_error = std::string("nmpc_create: no HIP device visible (hipGetDeviceCount: ") +
+                         hipGetErrorString(de) + ", count " + std::to_string(ndev) +
+                         "); this library has no CPU path";
+        return nullptr;
+    }
+    if (cfg->device < 0 || cfg->device >= ndev) return bad("nmpc_create: device ordinal out of range");
+    if (hipSetDevice(cfg->device) != hipSuccess) return bad("nmpc_create: hipSetDevice failed");
+    auto *s = new nmpc_solver();
+    s->cfg = *cfg;
+    s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
+    s->Bp = (cfg->max_batch + 63) / 64 * 64;
+    if (alloc_ws(s) != 0) {
+        g_create_error = s->err;
+        nmpc_destroy(s);
+        return nullptr;
+    }
+#ifdef NMPC_PROFILE
+    if (hipMalloc((void **)&s->d_prof, (size_t)8 * s->Bp * sizeof(long long)) != hipSuccess) s->d_prof = nullptr;
+#endif
+    for (auto &e : s->ev)
+        if (hipEventCreate(&e) != hipSuccess) { g_create_error = "hipEventCreate failed"; nmpc_destroy(s); return nullptr; }
+    const int N = cfg->N;
+    s->sx.assign((size_t)(N + 1) * NX, 0.0);
+    s->su.assign((size_t)N * NU, 0.0);
+    s->syref.assign((size_t)N * NY, 0.0);   // ocp.cost.yref = zeros, controller.py:244-245
+    s->syref_e.assign(NX, 0.0);
+    s->sx0.assign(NX, 0.0);                 // lbx_0 = ubx_0 = zeros, controller.py:254-255
+    return s;
+}
+
+void nmpc_destroy(nmpc_solver *s)
+{
+    if (!s) return;
+    (void)hipSetDevice(s->cfg.device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+                    s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
+    for (void *p : ptrs)
+        if (p) (void)hipFree(p);
+    for (auto &e : s->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete s;
+}
+
+const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+}  // extern "C"
+
+template <class T>
+static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
+                  const void *x_init, const void *u_init, void *u0, void *x_out, void *u_out, hipStream_t st)
+{
+    Consts<T> c;
+    fill_consts(s->cfg, c);
+    const bool cold = (x_init == nullptr || u_init == nullptr);
+    c.shared = (cold && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START)) ? 1 : 0;
+    Work<T> w;
+    w.Bp = s->Bp;
+    w.AB = (T *)s->AB; w.bv = (T *)s->bv; w.qr = (T *)s->qr; w.xl = (T *)s->xl; w.ul = (T *)s->ul;
+    w.LM = (T *)s->LM; w.iv = (T *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
+    w.prof = s->d_prof;
+    Inputs<T> in;
+    in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
+    in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
+    in.yref_bcast = bcast;
+    Outputs<T> out;
+    out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out;
+    const dim3 grid((B + 63) / 64), block(64);
+    HIP_TRY(s, hipEventRecord(s->ev[0], st));
+    hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
+    HIP_TRY(s, hipGetLastError());
+    HIP_TRY(s, hipEventRecord(s->ev[1], st));
+    hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
+    HIP_TRY(s, hipGetLastError());
+    HIP_TRY(s, hipEventRecord(s->ev[2], st));
+    s->last_B = B;
+    s->timed = true;
+    return 0;
+}
+
+extern "C" {
+
+int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e,
+                            int yref_bcast, const void *x_init, const void *u_init, void *u0,
+                            int32_t *status, void *x_out, void *u_out, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || B > s->cfg.max_batch) return s->fail(NMPC_EARG, "solve_batch: B=%d outside [1, max_batch=%d]", B, s->cfg.max_batch);
+    if (!x0 || !yref || !yref_e || !u0) return s->fail(NMPC_EARG, "solve_batch: x0, yref, yref_e and u0 are required");
+    if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "solve_batch: x_init and u_init must both be given or both be NULL");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    int rc = s->cfg.dtype == NMPC_DTYPE_F64
+                 ? launch<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, x_out, u_out, st)
+                 : launch<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, x_out, u_out, st);
+    if (rc) return rc;
+    if (status) HIP_TRY(s, hipMemcpyAsync(status, s->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+    return 0;
+}
+
+static int ensure_staging(nmpc_solver *s, size_t B)
+{
+    if (B <= s->staged_batch) return 0;
+    void **ps[] = {&s->s_x0, &s->s_yref, &s->s_yref_e, &s->s_xi, &s->s_ui, &s->s_u0, &s->s_xo, &s->s_uo};
+    for (void **p : ps)
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    const size_t N = (size_t)s->cfg.N, e = s->esz;
+    HIP_TRY(s, hipMalloc(&s->s_x0, B * NX * e));
+    HIP_TRY(s, hipMalloc(&s->s_yref, B * N * NY * e));
+    HIP_TRY(s, hipMalloc(&s->s_yref_e, B * NX * e));
+    HIP_TRY(s, hipMalloc(&s->s_xi, B * (N + 1) * NX * e));
+    HIP_TRY(s, hipMalloc(&s->s_ui, B * N * NU * e));
+    HIP_TRY(s, hipMalloc(&s->s_u0, B * NU * e));
+    HIP_TRY(s, hipMalloc(&s->s_xo, B * (N + 1) * NX * e));
+    HIP_TRY(s, hipMalloc(&s->s_uo, B * N * NU * e));
+    s->staged_batch = B;
+    return 0;
+}
+
+static int h2d(nmpc_solver *s, void *dst, const double *src, size_t n)
+{
+    if (s->esz == 8) {
+        HIP_TRY(s, hipMemcpy(dst, src, n * 8, hipMemcpyHostToDevice));
+    } else {
+        std::vector<float> tmp(n);
+        for (size_t i = 0; i < n; i++) tmp[i] = (float)src[i];
+        HIP_TRY(s, hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+static int d2h(nmpc_solver *s, double *dst, const void *src, size_t n)
+{
+    if (s->esz == 8) {
+        HIP_TRY(s, hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost));
+    } else {
+        std::vector<float> tmp(n);
+        HIP_TRY(s, hipMemcpy(tmp.data(), src, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
+    }
+    return 0;
+}
+
+int nmpc_solve_batch(nmpc_solver *s, int B, const double *x0, const double *yref, const double *yref_e,
+                     int yref_bcast, const double *x_init, const double *u_init, double *u0,
+                     int32_t *status, double *x_out, double *u_out)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || B > s->cfg.max_batch) return s->fail(NMPC_EARG, "solve_batch: B=%d outside [1, max_batch=%d]", B, s->cfg.max_batch);
+    if (!x0 || !yref || !yref_e || !u0) return s->fail(NMPC_EARG, "solve_batch: x0, yref, yref_e and u0 are required");
+    if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "solve_batch: x_init and u_init must both be given or both be NULL");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    int rc = ensure_staging(s, (size_t)B);
+    if (rc) return rc;
+    const size_t N = (size_t)s->cfg.N, Bs = (size_t)B;
+    if ((rc = h2d(s, s->s_x0, x0, Bs * NX))) return rc;
+    if ((rc = h2d(s, s->s_yref, yref, (yref_bcast ? 1 : Bs) * N * NY))) return rc;
+    if ((rc = h2d(s, s->s_yref_e, yref_e, (yref_bcast ? 1 : Bs) * NX))) return rc;
+    if (x_init) {
+        if ((rc = h2d(s, s->s_xi, x_init, Bs * (N + 1) * NX))) return rc;
+        if ((rc = h2d(s, s->s_ui, u_init, Bs * N * NU))) return rc;
+    }
+    rc = nmpc_solve_batch_device(s, B, s->s_x0, s->s_yref, s->s_yref_e, yref_bcast, x_init ? s->s_xi : nullptr,
+                                 x_init ? s->s_ui : nullptr, s->s_u0, nullptr, x_out ? s->s_xo : nullptr,
+                                 u_out ? s->s_uo : nullptr, nullptr);
+    if (rc) return rc;
+    HIP_TRY(s, hipDeviceSynchronize());
+    if ((rc = d2h(s, u0, s->s_u0, Bs * NU))) return rc;
+    if (status) HIP_TRY(s, hipMemcpy(status, s->d_status, Bs * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (x_out && (rc = d2h(s, x_out, s->s_xo, Bs * (N + 1) * NX))) return rc;
+    if (u_out && (rc = d2h(s, u_out, s->s_uo, Bs * N * NU))) return rc;
+    return 0;
+}
+
+// ---- single-instance AcadosOcpSolver surface (controller.py:412-460)
+static int slot(nmpc_solver *s, int stage, const char *field, int n, double **p, bool for_set)
+{
+    if (!s) return NMPC_EARG;
+    if (!field) return s->fail(NMPC_EARG, "field is NULL");
+    const int N = s->cfg.N;
+    const std::string f(field);
+    if (f == "x") {
+        if (stage < 0 || stage > N) return s->fail(NMPC_EARG, "stage %d out of range for 'x' (0..%d)", stage, N);
+        if (n != NX) return s->fail(NMPC_EARG, "'x' takes %d values, got %d", NX, n);
+        *p = &s->sx[(size_t)stage * NX];
+        return 0;
+    }
+    if (f == "u") {
+        if (stage < 0 || stage >= N) return s->fail(NMPC_EARG, "stage %d out of range for 'u' (0..%d)", stage, N - 1);
+        if (n != NU) return s->fail(NMPC_EARG, "'u' takes %d values, got %d", NU, n);
+        *p = &s->su[(size_t)stage * NU];
+        return 0;
+    }
+    if (!for_set) return s->fail(NMPC_EARG, "get: unknown field '%s' (known: x, u)", field);
+    if (f == "yref") {
+        if (stage < 0 || stage > N) return s->fail(NMPC_EARG, "stage %d out of range for 'yref' (0..%d)", stage, N);
+        const int want = stage < N ? NY : NX;
+        if (n != want) return s->fail(NMPC_EARG, "'yref' at stage %d takes %d values, got %d", stage, want, n);
+        *p = stage < N ? &s->syref[(size_t)stage * NY] : s->syref_e.data();
+        return 0;
+    }
+    if (f == "lbx" || f == "ubx") {
+        if (stage != 0)
+            return s->fail(NMPC_EARG, "'%s' is only supported at stage 0 (initial-state pin, controller.py:414-415); "
+                                      "path state bounds are the inactive +-1e6 box of controller.py:257-261", field);
+        if (n != NX) return s->fail(NMPC_EARG, "'%s' takes %d values, got %d", field, NX, n);
+        *p = s->sx0.data();
+        return 0;
+    }
+    return s->fail(NMPC_EARG, "set: unknown field '%s' (known: x, u, yref, lbx, ubx)", field);
+}
+
+int nmpc_set(nmpc_solver *s, int stage, const char *field, const double *value, int n)
+{
+    double *p = nullptr;
+    if (!s) return NMPC_EARG;
+    if (!value) return s->fail(NMPC_EARG, "set: value is NULL");
+    const int rc = slot(s, stage, field, n, &p, true);
+    if (rc) return rc;
+    std::memcpy(p, value, sizeof(double) * (size_t)n);
+    return 0;
+}
+
+int nmpc_get(nmpc_solver *s, int stage, const char *field, double *out, int n)
+{
+    double *p = nullptr;
+    if (!s) return NMPC_EARG;
+    if (!out) return s->fail(NMPC_EARG, "get: out is NULL");
+    const int rc = slot(s, stage, field, n, &p, false);
+    if (rc) return rc;
+    std::memcpy(out, p, sizeof(double) * (size_t)n);
+    return 0;
+}
+
+int nmpc_solve(nmpc_solver *s)
+{
+    if (!s) return NMPC_EARG;
+    const int N = s->cfg.N;
+    double u0[NU];
+    int32_t st = 0;
+    std::vector<double> xo((size_t)(N + 1) * NX), uo((size_t)N * NU);
+    // the linearisation point is whatever set('x'/'u') left in the slot (controller.py:416-431);
+    // the stage-0 state is pinned to lbx_0 = ubx_0 (controller.py:414-415)
+    const int rc = nmpc_solve_batch(s, 1, s->sx0.data(), s->syref.data(), s->syref_e.data(), 1, s->sx.data(),
+                                    s->su.data(), u0, &st, xo.data(), uo.data());
+    if (rc) return rc;
+    if (st == 0) { s->sx = xo; s->su = uo; }
+    return (int)st;
+}
+
+const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : nullptr; }
+
+#ifdef NMPC_PROFILE
+// diagnostic builds only (tools/profile_sweeps.py): int64 [8][Bp] DEVICE pointer and its row stride
+const long long *nmpc_debug_prof(nmpc_solver *s, int *stride) { if (stride) *stride = s->Bp; return s->d_prof; }
+#endif
+
+int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out)
+{
+    if (!s || !out) return NMPC_EARG;
+    std::memset(out, 0, sizeof(*out));
+    out->workspace_bytes = s->ws_bytes;
+    if (!s->timed) return 0;
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    HIP_TRY(s, hipDeviceSynchronize());
+    float a = 0, b = 0;
+    HIP_TRY(s, hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+    HIP_TRY(s, hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+    out->ms_prepare = a;
+    out->ms_solve = b;
+    const int B = s->last_B;
+    std::vector<int32_t> it(B), st(B);
+    HIP_TRY(s, hipMemcpy(it.data(), s->d_iters, (size_t)B * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(s, hipMemcpy(st.data(), s->d_status, (size_t)B * 4, hipMemcpyDeviceToHost));
+    out->batch = B;
+    out->iter_min = *std::min_element(it.begin(), it.end());
+    out->iter_max = *std::max_element(it.begin(), it.end());
+    double sum = 0;
+    for (int i = 0; i < B; i++) {
+        sum += it[i];
+        if (st[i] >= 0 && st[i] < 5) out->n_status[st[i]]++;
+    }
+    out->iter_mean = sum / B;
+    return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,54 @@
+// nmpc_consts.hpp -- host-side derivation of the per-solver constant block from nmpc_config.
+// (OCP definition controller.py:175-264; [UPSTREAM] U4 cost scaling, U5 Levenberg-Marquardt.)
+#pragma once
+
+#include <cstring>
+
+#include "../../include/rotors_nmpc.h"
+#include "nmpc_lane.hpp"
+
+namespace nmpc {
+
+template <class T>
+void fill_consts(const nmpc_config &g, Consts<T> &c)
+{
+    std::memset(&c, 0, sizeof(c));
+    c.N = g.N;
+    c.steps = g.sim_num_steps;
+    c.iter_max = g.qp_iter_max;
+    c.shared = 0;
+    c.dt = (T)g.dt;
+    c.h = (T)(g.dt / g.sim_num_steps);
+    const double sc = g.cost_scaled_by_dt ? g.dt : 1.0;                       // U4
+    const double lmk = g.levenberg_marquardt * (g.lm_scaled_by_dt ? g.dt : 1.0);  // U5
+    for (int i = 0; i < NX; i++) {
+        c.Qd[i] = (T)(sc * g.W[i] + lmk);
+        c.QdN[i] = (T)(g.W_e[i] + g.levenberg_marquardt);
+        c.Wq[i] = (T)(sc * g.W[i]);
+        c.WqN[i] = (T)g.W_e[i];
+    }
+    for (int i = 0; i < NU; i++) {
+        c.Rd[i] = (T)(sc * g.W[NX + i] + lmk);
+        c.Wr[i] = (T)(sc * g.W[NX + i]);
+        c.lbu[i] = (T)g.lbu[i];
+        c.ubu[i] = (T)g.ubu[i];
+        c.rx[i] = (T)g.rotor_x[i];
+        c.ry[i] = (T)g.rotor_y[i];
+        c.rz[i] = (T)g.rotor_z[i];
+        c.fuw[0][i] = (T)(g.rotor_y[i] / g.inertia[0]);
+        c.fuw[1][i] = (T)(-g.rotor_x[i] / g.inertia[1]);
+        c.fuw[2][i] = (T)(g.rotor_z[i] / g.inertia[2]);
+    }
+    c.inv_mass = (T)(1.0 / g.mass);
+    c.gravity = (T)g.gravity;
+    for (int i = 0; i < 3; i++) { c.J[i] = (T)g.inertia[i]; c.invJ[i] = (T)(1.0 / g.inertia[i]); }
+    c.tol_comp = (T)g.qp_tol_comp;
+    c.tol_stat = (T)g.qp_tol_stat;
+    c.mu0 = (T)g.qp_mu0;
+    c.tau = (T)g.qp_tau;
+    c.thr0 = (T)g.qp_thr0;
+    c.thr0_rel = (T)g.qp_thr0_rel;
+}
+
+
+}  // namespace nmpc

@@ -1,0 +1,325 @@
+// nmpc_ipm.hpp -- the two per-lane phases of one SQP real-time iteration:
+//
+//   lane_prepare   [UPSTREAM ocp_nlp_sqp_rti preparation]  staging of controller.py:414-445
+//                  (x0 pin, cold/warm initial trajectory, yref) + linearisation of every
+//                  shooting interval + LINEAR_LS Gauss-Newton gradients.
+//   lane_ipm       [UPSTREAM HPIPM]  Mehrotra predictor-corrector interior point method on the
+//                  OCP-QP with the Riccati factorisation of nmpc_lane.hpp, then the full SQP
+//                  step x += dx, u += du (controller.py:447, outputs read at :452-460).
+//
+// Same algorithm, same update rules and the same constants as oracle/nmpc_oracle.c
+// (ocpqp_ipm), restated for one-instance-per-lane execution:
+//   * feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
+//     states are implied by the affine dynamics -> the only residuals are stationarity
+//     (shrinks by 1-alpha per step, tracked as rho) and complementarity (mu);
+//   * each Newton system is an LQ problem in "absolute" form, solved by one backward and
+//     one forward Riccati sweep; the corrector re-uses the factorisation through a
+//     homogeneous sweep for the change of the input gradient;
+//   * the primal-dual update of an iteration is applied lazily inside the next backward
+//     sweep, so the small per-stage vectors cross memory once per sweep.
+#pragma once
+
+#include "nmpc_lane.hpp"
+
+namespace nmpc {
+
+// user-side arrays (row-major / AoS exactly as the C ABI takes them)
+template <class T>
+struct Inputs {
+    const T *x0;      // [B][13]
+    const T *yref;    // [B][N][17] or [N][17]
+    const T *yref_e;  // [B][13]    or [13]
+    const T *x_init;  // [B][N+1][13] or null
+    const T *u_init;  // [B][N][4]    or null
+    int yref_bcast;
+};
+
+template <class T>
+struct Outputs {
+    T *u0;            // [B][4]
+    T *x_out;         // [B][N+1][13] or null
+    T *u_out;         // [B][N][4] or null
+};
+
+template <class T>
+NMPC_HD void lane_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int lane)
+{
+    const int N = c.N, Bp = w.Bp;
+    const bool warm = in.x_init != nullptr && in.u_init != nullptr;
+    const T *x0 = in.x0 + (size_t)lane * NX;
+    const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)lane * N * NY;
+    const T *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)lane * NX;
+    const T *xi = warm ? in.x_init + (size_t)lane * (N + 1) * NX : nullptr;
+    const T *ui = warm ? in.u_init + (size_t)lane * N * NU : nullptr;
+
+    // trajectory staging (controller.py:414-431) and cost gradients (U4)
+    for (int k = 0; k <= N; k++) {
+        T xk[NX];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) {
+            xk[i] = (warm && k > 0) ? xi[(size_t)k * NX + i] : x0[i];   // stage 0 is pinned to x0
+            NMPC_ST(w.xl, k * NX + i, xk[i]);
+        }
+        if (k < N) {
+            NMPC_UNROLL for (int i = 0; i < NX; i++)
+                NMPC_ST(w.qr, k * QR_ROWS + i, c.Wq[i] * (xk[i] - yr[(size_t)k * NY + i]));
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                const T uk = warm ? ui[(size_t)k * NU + i] : T(0);
+                NMPC_ST(w.ul, k * NU + i, uk);
+                NMPC_ST(w.qr, k * QR_ROWS + NX + i, c.Wr[i] * (uk - yr[(size_t)k * NY + NX + i]));
+            }
+        } else {
+            NMPC_UNROLL for (int i = 0; i < NX; i++)
+                NMPC_ST(w.qr, N * QR_ROWS + i, c.WqN[i] * (xk[i] - ye[i]));
+        }
+    }
+    // linearisation (U2, U3): one interval if the cold start lets all stages share it
+    const int Ns = c.shared ? 1 : N;
+    for (int k = 0; k < Ns; k++) {
+        T xk[NX], uk[NU], xn[NX], S[11][NX];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xk[i] = NMPC_LD(w.xl, k * NX + i);
+        NMPC_UNROLL for (int i = 0; i < NU; i++) uk[i] = NMPC_LD(w.ul, k * NU + i);
+        erk_sens(c, xk, uk, xn, S);
+        T *ABk = w.AB + (size_t)k * AB_ROWS * Bp;
+        NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
+            NMPC_UNROLL for (int r = 0; r < ad_rows(cc); r++) NMPC_ST(ABk, ad_ofs(cc) + r, S[cc][r]);
+        }
+        NMPC_UNROLL for (int i = 0; i < NX; i++) {
+            NMPC_UNROLL for (int j = 0; j < NU; j++) NMPC_ST(ABk, AD_SIZE + i * NU + j, S[7 + j][i]);
+        }
+        NMPC_UNROLL for (int i = 0; i < NX; i++)
+            NMPC_ST(w.bv, k * NX + i, xn[i] - NMPC_LD(w.xl, (k + 1) * NX + i));
+    }
+}
+
+// per-pair Newton quantities shared by the sweeps
+template <class T>
+struct PairStep {
+    T dl, du;   // delta lambda_l, delta lambda_u
+};
+
+template <class T>
+NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out, int lane)
+{
+    const int N = c.N, Bp = w.Bp;
+    const T nc = T(2 * NU) * T(N);
+    const size_t abs_ = c.shared ? 0 : (size_t)AB_ROWS * Bp;
+    const size_t bs_ = c.shared ? 0 : (size_t)NX * Bp;
+    const size_t lms_ = (size_t)LM_ROWS * Bp, ivs_ = (size_t)IV_ROWS * Bp;
+
+    // ---- initial point: inputs pushed inside the box, perfectly centred multipliers
+    for (int k = 0; k < N; k++) {
+        T *ivk = w.iv + k * ivs_;
+        NMPC_UNROLL for (int i = 0; i < NU; i++) {
+            const T ul = NMPC_LD(w.ul, k * NU + i);
+            const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+            T thr = c.thr0;
+            if (c.thr0_rel * (hi - lo) > thr) thr = c.thr0_rel * (hi - lo);
+            if (hi - lo < T(2) * thr) thr = T(0.5) * (hi - lo);
+            T v = 0;
+            if (v - lo < thr) v = lo + thr;
+            if (hi - v < thr) v = hi - thr;
+            NMPC_ST(ivk, i, v);
+            NMPC_ST(ivk, 4 + i, c.mu0 / (v - lo));
+            NMPC_ST(ivk, 8 + i, c.mu0 / (hi - v));
+        }
+    }
+    NMPC_PROF_BEGIN
+    T mu = c.mu0, rho = T(1), alpha = 0, sigmu = 0;
+    int it = 0, status = 0;
+    bool pending = false;
+
+    for (;;) {
+        if (!(mu == mu)) { status = 1; break; }
+        if (mu <= c.tol_comp && rho <= c.tol_stat) break;
+        if (it >= c.iter_max) { status = 2; break; }
+        it++;
+        // ---- sweep A: (lazy update of the previous step) + backward factorisation,
+        //      affine right-hand side
+        T P[91], pv[NX];
+        NMPC_UNROLL for (int i = 0; i < 91; i++) P[i] = 0;
+        NMPC_UNROLL for (int i = 0; i < NX; i++) { P[sidx(i, i)] = c.QdN[i]; pv[i] = NMPC_LD(w.qr, N * QR_ROWS + i); }
+        bool ok = true;
+        T musum = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            T *ivk = w.iv + k * ivs_;
+            T D[NU], rh[NU];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                const T ul = NMPC_LD(w.ul, k * NU + i);
+                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+                T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                if (pending) {
+                    const T tl = u - lo, tu = hi - u;
+                    const T da = NMPC_LD(ivk, 12 + i) - u, d = NMPC_LD(ivk, 16 + i);
+                    const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                    const T cl = dla * da, cu = -dua * da;
+                    const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
+                    const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
+                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
+                    NMPC_ST(ivk, i, u); NMPC_ST(ivk, 4 + i, ll); NMPC_ST(ivk, 8 + i, lu);
+                }
+                const T tl = u - lo, tu = hi - u;
+                musum += ll * tl + lu * tu;
+                const T sg = ll / tl + lu / tu;
+                D[i] = c.Rd[i] + sg;
+                rh[i] = NMPC_LD(w.qr, k * QR_ROWS + NX + i) - sg * u;
+            }
+            ok &= ricc_factor_stage(c, P, pv, w.AB + k * abs_, w.bv + k * bs_, w.qr + (size_t)k * QR_ROWS * Bp,
+                                    D, rh, w.LM + k * lms_, Bp, lane, k == 0);
+        }
+        pending = false;
+        NMPC_STAMP(0)
+        mu = musum / nc;   // exact duality measure of the current iterate
+        if (!ok) { status = (mu == mu) ? 4 : 1; break; }
+        // ---- sweep B: forward affine solve, step length and mu of the affine step
+        T xh[NX], uh[NU];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = 0;
+        T aaff = T(1), s2 = 0;
+        for (int k = 0; k < N; k++) {
+            T *ivk = w.iv + k * ivs_;
+            ricc_forward_stage(c, xh, uh, w.AB + k * abs_, w.bv + k * bs_, w.LM + k * lms_, Bp, lane,
+                               true, k == 0, k == N - 1);
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                const T ul = NMPC_LD(w.ul, k * NU + i);
+                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                NMPC_ST(ivk, 12 + i, uh[i]);
+                const T tl = u - lo, tu = hi - u, d = uh[i] - u;
+                const T dla = -ll - ll / tl * d, dua = -lu + lu / tu * d;
+                if (d < T(0) && -tl / d < aaff) aaff = -tl / d;
+                if (d > T(0) && tu / d < aaff) aaff = tu / d;
+                if (dla < T(0) && -ll / dla < aaff) aaff = -ll / dla;
+                if (dua < T(0) && -lu / dua < aaff) aaff = -lu / dua;
+                s2 += dla * d - dua * d;
+            }
+        }
+        NMPC_STAMP(1)
+        // sum_i (lam + a dlam)(t + a dt) = (1 - a) sum lam t + a^2 sum dlam dt   (sigma = 0)
+        const T muaff = (T(1) - aaff) * mu + aaff * aaff * s2 / nc;
+        T sg3 = muaff / mu;
+        sg3 = sg3 * sg3 * sg3;
+        sigmu = sg3 * mu;
+        // ---- sweep D: backward homogeneous solve for the corrector's gradient change
+        NMPC_UNROLL for (int i = 0; i < NX; i++) pv[i] = 0;
+        for (int k = N - 1; k >= 0; k--) {
+            T *ivk = w.iv + k * ivs_;
+            T dr[NU];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                const T ul = NMPC_LD(w.ul, k * NU + i);
+                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                const T tl = u - lo, tu = hi - u, da = NMPC_LD(ivk, 12 + i) - u;
+                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                const T cl = dla * da, cu = -dua * da;
+                dr[i] = -(sigmu - cl) / tl + (sigmu - cu) / tu;
+            }
+            ricc_back_homog_stage(c, pv, w.AB + k * abs_, dr, w.LM + k * lms_, Bp, lane, k == 0);
+        }
+        NMPC_STAMP(2)
+        // ---- sweep E: forward homogeneous solve, final direction, step length
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = 0;
+        T amax = T(1e30);
+        for (int k = 0; k < N; k++) {
+            T *ivk = w.iv + k * ivs_;
+            ricc_forward_stage(c, xh, uh, w.AB + k * abs_, w.bv + k * bs_, w.LM + k * lms_, Bp, lane,
+                               false, k == 0, k == N - 1);
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                const T ul = NMPC_LD(w.ul, k * NU + i);
+                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                const T tl = u - lo, tu = hi - u, da = NMPC_LD(ivk, 12 + i) - u;
+                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                const T cl = dla * da, cu = -dua * da;
+                const T d = da + uh[i];
+                NMPC_ST(ivk, 16 + i, d);
+                const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
+                const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
+                if (d < T(0) && -tl / d < amax) amax = -tl / d;
+                if (d > T(0) && tu / d < amax) amax = tu / d;
+                if (dl < T(0) && -ll / dl < amax) amax = -ll / dl;
+                if (du < T(0) && -lu / du < amax) amax = -lu / du;
+            }
+        }
+        NMPC_STAMP(3)
+        alpha = c.tau * amax;
+        if (alpha > T(1)) alpha = T(1);
+        if (!(alpha == alpha)) { status = 1; break; }
+        if (alpha < T(1e-12)) { status = 3; break; }
+        pending = true;
+        rho *= (T(1) - alpha);
+        // duality measure after the step, for the termination test only (sweep A recomputes
+        // it exactly): apply the update to a running sum
+        {
+            T ms = 0;
+            for (int k = 0; k < N; k++) {
+                T *ivk = w.iv + k * ivs_;
+                NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                    const T ul = NMPC_LD(w.ul, k * NU + i);
+                    const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
+                    const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                    const T tl = u - lo, tu = hi - u;
+                    const T da = NMPC_LD(ivk, 12 + i) - u, d = NMPC_LD(ivk, 16 + i);
+                    const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                    const T cl = dla * da, cu = -dua * da;
+                    const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
+                    const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
+                    ms += (ll + alpha * dl) * (tl + alpha * d) + (lu + alpha * du) * (tu - alpha * d);
+                }
+            }
+            mu = ms / nc;
+        }
+        NMPC_STAMP(4)
+    }
+
+    NMPC_STAMP(5)
+    // ---- final sweep: pending update of the inputs, state rollout, full SQP step (U1)
+    {
+        T dx[NX];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) dx[i] = 0;
+        bool bad = false;
+        for (int k = 0; k < N; k++) {
+            T *ivk = w.iv + k * ivs_;
+            T du[NU];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) {
+                T u = NMPC_LD(ivk, i);
+                if (pending) u += alpha * NMPC_LD(ivk, 16 + i);
+                du[i] = u;
+                bad |= !(u == u);
+            }
+            T Ad[AD_SIZE], Bm[NX][NU], y[NX];
+            const T *ABk = w.AB + k * abs_;
+            load_ad(ABk, Bp, lane, Ad);
+            load_b(ABk, Bp, lane, Bm);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) y[i] = NMPC_LD(w.bv + k * bs_, i);
+            a_mul_add(c, Ad, Bm, dx, du, y);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) { dx[i] = y[i]; bad |= !(y[i] == y[i]); }
+            if (status == 0 || status == 2) {
+                NMPC_UNROLL for (int i = 0; i < NU; i++) NMPC_ST(w.ul, k * NU + i, NMPC_LD(w.ul, k * NU + i) + du[i]);
+                NMPC_UNROLL for (int i = 0; i < NX; i++)
+                    NMPC_ST(w.xl, (k + 1) * NX + i, NMPC_LD(w.xl, (k + 1) * NX + i) + dx[i]);
+            }
+        }
+        if (bad && (status == 0 || status == 2)) status = 1;
+    }
+    NMPC_STAMP(6)
+    NMPC_PROF_END(w)
+    // acados RTI tolerates a QP that stopped at its iteration cap (U10)
+    const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
+    w.iters[lane] = it;
+    w.status[lane] = nlp_status;
+    NMPC_UNROLL for (int i = 0; i < NU; i++)
+        out.u0[(size_t)lane * NU + i] = nlp_status == 0 ? NMPC_LD(w.ul, i) : T(0);   // controller.py:448-452
+    if (out.x_out) {
+        for (int k = 0; k <= N; k++) {
+            NMPC_UNROLL for (int i = 0; i < NX; i++)
+                out.x_out[((size_t)lane * (N + 1) + k) * NX + i] = NMPC_LD(w.xl, k * NX + i);
+        }
+    }
+    if (out.u_out) {
+        for (int k = 0; k < N; k++) {
+            NMPC_UNROLL for (int i = 0; i < NU; i++)
+                out.u_out[((size_t)lane * N + k) * NU + i] = NMPC_LD(w.ul, k * NU + i);
+        }
+    }
+}
+
+}  // namespace nmpc

@@ -1,0 +1,133 @@
+"""`AcadosOcpSolver`-shaped front end of the MI355X-native solver.
+
+Mirrors exactly the surface the reference uses on the object it builds at
+/root/reference/src/rotors_mpc_controller/controller.py:263 --
+``set(stage, field, value)`` (:414-445), ``solve()`` (:447), ``get(stage, field)`` (:452-460)
+-- and adds the batched entry points the reference does not have.  All arithmetic happens in
+librotors_nmpc_hip.so on the GPU; this module only marshals arrays.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _lib
+from ._lib import NU, NX, NY, NmpcConfig, NmpcStats
+
+
+class NmpcError(RuntimeError):
+    pass
+
+
+def _dp(a: Optional[np.ndarray]):
+    return None if a is None else a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _f64(a, shape=None) -> np.ndarray:
+    out = np.ascontiguousarray(a, dtype=np.float64)
+    if shape is not None and tuple(out.shape) != tuple(shape):
+        raise ValueError(f"expected shape {tuple(shape)}, got {tuple(out.shape)}")
+    return out
+
+
+class NmpcOcpSolver:
+    """Drop-in for ``acados_template.AcadosOcpSolver`` on the reference's hot path.
+
+    Construct from an :class:`NmpcConfig` (numbers instead of a CasADi/AcadosOcp object: the
+    reference bakes the physical constants into a symbolic expression, controller.py:311-341).
+    """
+
+    def __init__(self, config: NmpcConfig):
+        self._lib = _lib.load()
+        self.config = config
+        self._h = self._lib.nmpc_create(C.byref(config))
+        if not self._h:
+            raise NmpcError(self._lib.nmpc_last_error(None).decode())
+        self.N = int(config.N)
+        self.status = 0
+
+    # -- lifetime ------------------------------------------------------------------------
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            self._lib.nmpc_destroy(self._h)
+            self._h = None
+
+    def __del__(self):  # controller.py:169-170 relies on `del old_solver`
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int) -> None:
+        if rc < 0:
+            raise NmpcError(self._lib.nmpc_last_error(self._h).decode())
+
+    # -- AcadosOcpSolver surface ---------------------------------------------------------
+    def set(self, stage: int, field: str, value) -> None:
+        v = np.ascontiguousarray(value, dtype=np.float64).reshape(-1)
+        self._check(self._lib.nmpc_set(self._h, int(stage), field.encode(), _dp(v), int(v.size)))
+
+    def get(self, stage: int, field: str) -> np.ndarray:
+        n = {"x": NX, "u": NU}.get(field)
+        if n is None:
+            raise NmpcError(f"get: unknown field '{field}' (known: x, u)")
+        out = np.zeros(n)
+        self._check(self._lib.nmpc_get(self._h, int(stage), field.encode(), _dp(out), n))
+        return out
+
+    def solve(self) -> int:
+        rc = self._lib.nmpc_solve(self._h)
+        self._check(rc)
+        self.status = rc
+        return rc
+
+    # -- batched entry points (no counterpart in the reference) ----------------------------
+    def solve_batch(self, x0, yref, yref_e, x_init=None, u_init=None, want_traj: bool = False):
+        """Host arrays in, host arrays out (PCIe inclusive).  yref [N,17] (shared) or [B,N,17]."""
+        x0 = _f64(x0)
+        if x0.ndim != 2 or x0.shape[1] != NX:
+            raise ValueError(f"x0 must be [B,{NX}]")
+        B, N = x0.shape[0], self.N
+        yref = _f64(yref)
+        bcast = yref.ndim == 2
+        yref = _f64(yref, (N, NY) if bcast else (B, N, NY))
+        yref_e = _f64(yref_e, (NX,) if bcast else (B, NX))
+        if (x_init is None) != (u_init is None):
+            raise ValueError("x_init and u_init must both be given or both be None")
+        xi = None if x_init is None else _f64(x_init, (B, N + 1, NX))
+        ui = None if u_init is None else _f64(u_init, (B, N, NU))
+        u0 = np.zeros((B, NU))
+        status = np.zeros(B, dtype=np.int32)
+        xo = np.zeros((B, N + 1, NX)) if want_traj else None
+        uo = np.zeros((B, N, NU)) if want_traj else None
+        rc = self._lib.nmpc_solve_batch(self._h, B, _dp(x0), _dp(yref), _dp(yref_e), int(bcast), _dp(xi),
+                                        _dp(ui), _dp(u0), status.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        _dp(xo), _dp(uo))
+        self._check(rc)
+        return dict(u0=u0, status=status, x=xo, u=uo)
+
+    def solve_batch_device(self, B: int, x0_ptr: int, yref_ptr: int, yref_e_ptr: int, yref_bcast: bool,
+                           u0_ptr: int, status_ptr: int = 0, x_init_ptr: int = 0, u_init_ptr: int = 0,
+                           x_out_ptr: int = 0, u_out_ptr: int = 0, stream: int = 0) -> None:
+        """Device pointers (e.g. ``tensor.data_ptr()``) of element type config.dtype; only enqueues."""
+        rc = self._lib.nmpc_solve_batch_device(self._h, int(B), x0_ptr, yref_ptr, yref_e_ptr, int(yref_bcast),
+                                               x_init_ptr or None, u_init_ptr or None, u0_ptr,
+                                               status_ptr or None, x_out_ptr or None, u_out_ptr or None,
+                                               stream or None)
+        self._check(rc)
+
+    def device_iterations_ptr(self) -> int:
+        return int(self._lib.nmpc_device_iterations(self._h) or 0)
+
+    def stats(self) -> dict:
+        st = NmpcStats()
+        self._check(self._lib.nmpc_get_stats(self._h, C.byref(st)))
+        return dict(batch=st.batch, iter_min=st.iter_min, iter_max=st.iter_max, iter_mean=st.iter_mean,
+                    n_status=list(st.n_status), ms_prepare=st.ms_prepare, ms_solve=st.ms_solve,
+                    workspace_bytes=int(st.workspace_bytes))
+
+
+# name a maintainer would import in place of acados_template's class
+AcadosOcpSolver = NmpcOcpSolver

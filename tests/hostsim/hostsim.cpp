@@ -1,0 +1,53 @@
+// hostsim.cpp -- TEST-ONLY harness: compiles the per-lane kernel bodies of
+// rotors_mpc_controller_amd/csrc/nmpc_{lane,ipm}.hpp for the host and runs them lane by lane
+// over the same SoA workspace layout the GPU uses.  Lets the `-m "not gpu"` suite check the
+// kernel arithmetic against the oracle without a GPU.  It is NOT linked into, loaded by, or
+// reachable from the product library (librotors_nmpc_hip.so has no CPU path).
+#include <cstdint>
+#include <cstring>
+#include <vector>
+
+#include "../../include/rotors_nmpc.h"
+#include "../../rotors_mpc_controller_amd/csrc/nmpc_consts.hpp"
+#include "../../rotors_mpc_controller_amd/csrc/nmpc_ipm.hpp"
+
+using namespace nmpc;
+
+template <class T>
+static void run(const nmpc_config &g, int B, const double *x0, const double *yref, const double *yref_e,
+                int bcast, const double *x_init, const double *u_init, double *u0, int32_t *status,
+                double *x_out, double *u_out, int32_t *iters, int shared)
+{
+    const size_t N = g.N, Bp = (B + 63) / 64 * 64;
+    Consts<T> c;
+    fill_consts(g, c);
+    c.shared = (shared && !x_init) ? 1 : 0;
+    auto cv = [](const double *p, size_t n) { std::vector<T> v(n); for (size_t i = 0; i < n; i++) v[i] = (T)p[i]; return v; };
+    std::vector<T> hx0 = cv(x0, (size_t)B * NX), hy = cv(yref, (bcast ? 1 : B) * N * NY),
+                   hye = cv(yref_e, (bcast ? 1 : B) * NX);
+    std::vector<T> hxi, hui;
+    if (x_init) { hxi = cv(x_init, (size_t)B * (N + 1) * NX); hui = cv(u_init, (size_t)B * N * NU); }
+    std::vector<T> AB(N * AB_ROWS * Bp), bv(N * NX * Bp), qr((N * QR_ROWS + NX) * Bp), xl((N + 1) * NX * Bp),
+        ul(N * NU * Bp), LM(N * LM_ROWS * Bp), iv(N * IV_ROWS * Bp);
+    std::vector<int32_t> it(Bp), st(Bp);
+    std::vector<T> ou0((size_t)B * NU), oxo((size_t)B * (N + 1) * NX), ouo((size_t)B * N * NU);
+    Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), it.data(), st.data(), nullptr};
+    Inputs<T> in{hx0.data(), hy.data(), hye.data(), x_init ? hxi.data() : nullptr, x_init ? hui.data() : nullptr, bcast};
+    Outputs<T> out{ou0.data(), oxo.data(), ouo.data()};
+    for (int lane = 0; lane < B; lane++) lane_prepare(c, w, in, lane);
+    for (int lane = 0; lane < B; lane++) lane_ipm(c, w, out, lane);
+    for (size_t i = 0; i < ou0.size(); i++) u0[i] = ou0[i];
+    if (x_out) for (size_t i = 0; i < oxo.size(); i++) x_out[i] = oxo[i];
+    if (u_out) for (size_t i = 0; i < ouo.size(); i++) u_out[i] = ouo[i];
+    for (int i = 0; i < B; i++) { if (status) status[i] = st[i]; if (iters) iters[i] = it[i]; }
+}
+
+extern "C" int hostsim_solve_batch(const nmpc_config *g, int B, const double *x0, const double *yref,
+                                   const double *yref_e, int bcast, const double *x_init, const double *u_init,
+                                   double *u0, int32_t *status, double *x_out, double *u_out, int32_t *iters)
+{
+    const int shared = (g->flags & NMPC_FLAG_SHARE_COLD_START) ? 1 : 0;
+    if (g->dtype == NMPC_DTYPE_F64) run<double>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);
+    else run<float>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);
+    return 0;
+}
