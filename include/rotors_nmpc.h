@@ -43,6 +43,8 @@ extern "C" {
 
 /* flags */
 #define NMPC_FLAG_SHARE_COLD_START 1u /* cold start: all stages share one (A,B,b); linearise once */
+#define NMPC_FLAG_TEAM_MAPPING 2u     /* QP phase: 16 lanes cooperate on one instance (small batches)
+                                         instead of one instance per lane (large batches) */
 
 /* Everything controller.py:175-264 hands to AcadosOcp, plus the physical constants that the
  * reference bakes into the CasADi expression (controller.py:311-341), as plain numbers.   */

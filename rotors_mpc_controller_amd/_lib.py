@@ -14,6 +14,7 @@ NX, NU, NY = 13, 4, 17
 
 DTYPE_F64, DTYPE_F32 = 0, 1
 FLAG_SHARE_COLD_START = 1
+FLAG_TEAM_MAPPING = 2
 
 STATUS_NAMES = {0: "SUCCESS", 1: "NAN_DETECTED", 2: "MAXITER", 3: "MINSTEP", 4: "QP_FAILURE"}
 

@@ -1,0 +1,200 @@
+"""GPU parity tests proper (-m gpu): the HIP path, called through the C ABI, against the CPU
+oracle on identical seeded inputs.  FP64 tolerance: |u0 - oracle| <= 1e-9 absolute (thrusts are
+O(1) N, so this is well inside the 1e-6 relative target of BASELINE.json); same algorithm on
+both sides, so the observed differences are rounding-level (~1e-14).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rotors_mpc_controller_amd import _lib
+from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
+
+pytestmark = pytest.mark.gpu
+
+TOL_U = 1e-9
+TOL_X = 1e-8
+WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
+
+
+def make_solver(**over):
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    over.setdefault("max_batch", 512)
+    return NmpcOcpSolver(_lib.default_config(**over))
+
+
+def oracle_cfg(**over):
+    return O.default_config(qp_gamma=0.0, **over)
+
+
+def hover(cfg):
+    return hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
+
+
+@pytest.mark.parametrize("mapping", ["lane", "team"])
+@pytest.mark.parametrize("dist,seed", [(NEAR_HOVER, 0), (AGGRESSIVE, 1), (WILD, 2)])
+@pytest.mark.parametrize("share", [True, False])
+def test_cold_start_batch_matches_oracle(dist, seed, share, mapping):
+    s = make_solver(flags=(1 if share else 0) | (_lib.FLAG_TEAM_MAPPING if mapping == "team" else 0))
+    x0 = sample_x0(300, seed, **dist)          # ragged: not a multiple of the wave size
+    yref, ye = hover(s.config)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    ref = O.solve_batch(oracle_cfg(), x0, yref, ye, want_traj=True)
+    assert (out["status"] == 0).all() and (ref["status"] == 0).all()
+    np.testing.assert_allclose(out["u0"], ref["u0"], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(out["x"], ref["x"], rtol=0, atol=TOL_X)
+    np.testing.assert_allclose(out["u"], ref["u"], rtol=0, atol=TOL_X)
+    st = s.stats()
+    assert st["batch"] == 300 and st["n_status"][0] == 300
+    assert abs(st["iter_mean"] - ref["iters"].mean()) < 0.05
+
+
+@pytest.mark.parametrize("mapping", ["lane", "team"])
+def test_per_instance_yref_and_warm_start(mapping):
+    """[B,N,17] references + a second RTI from the previous solution (controller.py:419-424)."""
+    s = make_solver(flags=1 | (_lib.FLAG_TEAM_MAPPING if mapping == "team" else 0))
+    c = oracle_cfg()
+    B = 96
+    x0 = sample_x0(B, 5, **AGGRESSIVE)
+    rng = np.random.default_rng(5)
+    yref, ye = hover(s.config)
+    yref = np.tile(yref, (B, 1, 1)); ye = np.tile(ye, (B, 1))
+    yref[:, :, 0:3] += rng.normal(0, 0.2, (B, 1, 3))       # per-instance setpoints
+    ye[:, 0:3] = yref[:, 0, 0:3]
+    o1 = s.solve_batch(x0, yref, ye, want_traj=True)
+    r1 = O.solve_batch(c, x0, yref, ye, want_traj=True)
+    np.testing.assert_allclose(o1["u0"], r1["u0"], rtol=0, atol=TOL_U)
+    x1 = x0 + rng.normal(0, 0.01, x0.shape)                # the plant moved a little
+    o2 = s.solve_batch(x1, yref, ye, x_init=o1["x"], u_init=o1["u"], want_traj=True)
+    r2 = O.solve_batch(c, x1, yref, ye, x_init=r1["x"], u_init=r1["u"], want_traj=True)
+    assert (o2["status"] == 0).all()
+    np.testing.assert_allclose(o2["u0"], r2["u0"], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(o2["x"], r2["x"], rtol=0, atol=TOL_X)
+
+
+@pytest.mark.parametrize("mapping", ["lane", "team"])
+def test_golden_fixture(mapping):
+    """Committed inputs/outputs (tests/golden/rti_cold_start.npz, made by make_golden.py)."""
+    from pathlib import Path
+    g = np.load(Path(__file__).parent / "golden" / "rti_cold_start.npz")
+    s = make_solver(flags=1 | (_lib.FLAG_TEAM_MAPPING if mapping == "team" else 0))
+    out = s.solve_batch(g["x0"], g["yref"], g["yref_e"], want_traj=True)
+    np.testing.assert_array_equal(out["status"], g["status"])
+    np.testing.assert_allclose(out["u0"], g["u0"], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(out["x"], g["x"], rtol=0, atol=TOL_X)
+
+
+def test_known_answers_on_gpu():
+    hov = 0.68 * 9.81 / 4.0
+    xh = np.zeros(13); xh[2] = 1.0; xh[6] = 1.0
+    # K1: hover, LM = 0 -> exactly m g / 4
+    s = make_solver(levenberg_marquardt=0.0)
+    yref, ye = hover(s.config)
+    out = s.solve_batch(xh[None], yref, ye)
+    np.testing.assert_allclose(out["u0"], hov, atol=1e-10)
+    # K3: pure z offset -> four equal thrusts, 2.19447 N
+    s = make_solver()
+    x = xh.copy(); x[2] = 0.5
+    out = s.solve_batch(x[None], yref, ye)
+    assert np.ptp(out["u0"]) < 1e-12 and abs(out["u0"][0, 0] - 2.19447) < 1e-5
+
+
+def test_status_paths_on_gpu():
+    s = make_solver()
+    yref, ye = hover(s.config)
+    x0 = sample_x0(70, 7, **NEAR_HOVER)
+    x0[3, 4] = np.nan                          # one poisoned lane must not hurt its wave
+    out = s.solve_batch(x0, yref, ye)
+    ref = O.solve_batch(oracle_cfg(), x0, yref, ye)
+    assert out["status"][3] == 1 and (np.delete(out["status"], 3) == 0).all()
+    np.testing.assert_array_equal(out["u0"][3], 0.0)        # controller.py:448-450
+    np.testing.assert_allclose(np.delete(out["u0"], 3, 0), np.delete(ref["u0"], 3, 0), atol=TOL_U)
+    # iteration cap 1: tolerated like acados RTI, result = oracle's one-iteration result
+    s1 = make_solver(qp_iter_max=1)
+    o = s1.solve_batch(x0[:3], yref, ye)
+    r = O.solve_batch(oracle_cfg(qp_iter_max=1), x0[:3], yref, ye)
+    np.testing.assert_array_equal(o["status"], r["status"])
+    np.testing.assert_allclose(o["u0"][:3][o["status"] == 0], r["u0"][:3][r["status"] == 0], atol=TOL_U)
+
+
+def test_single_instance_set_solve_get_surface():
+    """The exact call sequence of PositionNMPC.solve (controller.py:412-460)."""
+    s = make_solver(max_batch=1)
+    c = oracle_cfg()
+    N = s.N
+    yref, ye = hover(s.config)
+    x0 = sample_x0(1, 9, **AGGRESSIVE)[0]
+    s.set(0, "lbx", x0); s.set(0, "ubx", x0); s.set(0, "x", x0)
+    s.set(0, "u", np.zeros(4))
+    for k in range(1, N):
+        s.set(k, "x", x0); s.set(k, "u", np.zeros(4))
+    s.set(N, "x", x0)
+    for k in range(N):
+        s.set(k, "yref", yref[k])
+    s.set(N, "yref", ye)
+    assert s.solve() == 0
+    u0 = s.get(0, "u")
+    ref = O.solve_batch(c, x0[None], yref, ye, want_traj=True)
+    np.testing.assert_allclose(u0, ref["u0"][0], atol=TOL_U)
+    np.testing.assert_allclose(s.get(N, "x"), ref["x"][0, N], atol=TOL_X)
+    np.testing.assert_allclose(s.get(N - 1, "u"), ref["u"][0, N - 1], atol=TOL_X)
+
+
+def test_long_horizon_and_odd_sizes():
+    for N, B in ((3, 5), (60, 33)):
+        s = make_solver(N=N, max_batch=64)
+        c = oracle_cfg(N=N)
+        yref, ye = hover(s.config)
+        x0 = sample_x0(B, N, **AGGRESSIVE)
+        out = s.solve_batch(x0, yref, ye)
+        ref = O.solve_batch(c, x0, yref, ye)
+        np.testing.assert_allclose(out["u0"], ref["u0"], atol=TOL_U)
+
+
+def test_full_size_properties_batch_4096():
+    """BASELINE config 2 at full size: oracle on a sample, plus size-independent properties."""
+    s = make_solver(max_batch=4096)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(4096, 0, **NEAR_HOVER)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    assert (out["status"] == 0).all()
+    lbu, ubu = np.array(s.config.lbu), np.array(s.config.ubu)
+    assert (out["u"] >= lbu - 1e-12).all() and (out["u"] <= ubu + 1e-12).all()
+    np.testing.assert_array_equal(out["x"][:, 0], x0)                    # x0 pin (U7)
+    # permutation equivariance: instances are independent
+    perm = np.random.default_rng(0).permutation(4096)
+    out_p = s.solve_batch(x0[perm], yref, ye)
+    np.testing.assert_array_equal(out_p["u0"], out["u0"][perm])
+    # broadcast and materialised references agree bit for bit
+    out_m = s.solve_batch(x0, np.tile(yref, (4096, 1, 1)), np.tile(ye, (4096, 1)))
+    np.testing.assert_array_equal(out_m["u0"], out["u0"])
+    idx = np.arange(0, 4096, 16)
+    ref = O.solve_batch(oracle_cfg(), x0[idx], yref, ye)
+    np.testing.assert_allclose(out["u0"][idx], ref["u0"], atol=TOL_U)
+
+
+def test_fp32_variant_is_close():
+    """Config 3 arithmetic: FP32 end to end; stated tolerance 5e-3 N on u0 (no FP64 refinement)."""
+    s = make_solver(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(256, 1, **NEAR_HOVER)
+    out = s.solve_batch(x0, yref, ye)
+    ref = O.solve_batch(oracle_cfg(), x0, yref, ye)
+    assert (out["status"] == 0).all()
+    assert np.abs(out["u0"] - ref["u0"]).max() < 5e-3
+
+
+def test_argument_errors_raise():
+    from rotors_mpc_controller_amd.solver import NmpcError
+    s = make_solver(max_batch=8)
+    yref, ye = hover(s.config)
+    with pytest.raises(NmpcError):
+        s.solve_batch(sample_x0(9, 0), yref, ye)             # B > max_batch
+    with pytest.raises(NmpcError):
+        s.set(0, "nope", np.zeros(13))
+    with pytest.raises(NmpcError):
+        s.set(99, "x", np.zeros(13))
+    with pytest.raises(NmpcError):
+        s.set(0, "x", np.zeros(5))
+    with pytest.raises(NmpcError):
+        s.set(3, "lbx", np.zeros(13))
