@@ -78,6 +78,8 @@ def main() -> None:
     ap.add_argument("--yref", choices=["per_instance", "broadcast"], default="per_instance")
     ap.add_argument("--no-share", action="store_true", help="do not exploit the shared cold-start linearisation")
     ap.add_argument("--traj-out", action="store_true", help="also write the full x/u trajectories")
+    ap.add_argument("--mapping", choices=["team", "lane"], default="team",
+                    help="QP phase: 16 lanes per instance (team) or one instance per lane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
@@ -103,9 +105,10 @@ def main() -> None:
     tdt, npdt, esz = (torch.float64, np.float64, 8) if args.dtype == "f64" else (torch.float32, np.float32, 4)
     cfg = _lib.default_config(N=N, max_batch=B, device=local,
                               dtype=_lib.DTYPE_F64 if args.dtype == "f64" else _lib.DTYPE_F32,
-                              flags=0 if args.no_share else _lib.FLAG_SHARE_COLD_START)
+                              flags=(0 if args.no_share else _lib.FLAG_SHARE_COLD_START)
+                              | (_lib.FLAG_TEAM_MAPPING if args.mapping == "team" else 0))
     if args.dtype == "f32":
-        cfg.update(qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+        cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
     solver = NmpcOcpSolver(cfg)
     hover = cfg.mass * cfg.gravity / 4.0
     seed = 0 if world == 1 else 100 + rank                      # config 2 / config 4
@@ -174,7 +177,7 @@ def main() -> None:
         # streamed solver workspace per solve (kernel table): rows read+written per stage and IPM iteration
         ws_rows = 820 if args.no_share else 420
         ws_gbs = (n_ipm * N * ws_rows * esz) * B / kern_s / 1e9
-        roof = dict(bound="hbm", kernel="k_ipm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+        roof = dict(bound="hbm", kernel="k_team_ipm" if args.mapping == "team" else "k_ipm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=hbm_alg_gbs / HBM_PEAK_GBS, traffic=None,
                     kernel_ms=st["ms_solve"], prepare_ms=st["ms_prepare"], algorithmic_bytes_per_solve=alg_b,
                     workspace_model_gbs=ws_gbs,
@@ -186,7 +189,7 @@ def main() -> None:
                     vs_baseline=None, dtype=args.dtype, data="synthetic",
                     config=dict(workload=f"batch={B} random x0 around hover ({args.dist}, seed {seed}), N={N}, "
                                          f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
-                                batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share,
+                                batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
                                 traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather u0"),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
                     status_histogram=st["n_status"], roofline=roof)

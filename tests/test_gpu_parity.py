@@ -175,7 +175,7 @@ def test_full_size_properties_batch_4096():
 
 def test_fp32_variant_is_close():
     """Config 3 arithmetic: FP32 end to end; stated tolerance 5e-3 N on u0 (no FP64 refinement)."""
-    s = make_solver(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+    s = make_solver(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
     yref, ye = hover(s.config)
     x0 = sample_x0(256, 1, **NEAR_HOVER)
     out = s.solve_batch(x0, yref, ye)

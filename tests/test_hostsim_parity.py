@@ -60,7 +60,7 @@ def test_warm_start_and_switches():
 
 
 def test_fp32_kernel_arithmetic_is_close():
-    cfg = _lib.default_config(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+    cfg = _lib.default_config(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
     yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
     x0 = sample_x0(32, 1, **NEAR_HOVER)
     out = H.solve_batch(cfg, x0, yref, ye)

@@ -33,7 +33,7 @@ B = a.batch
 cfg = _lib.default_config(max_batch=B, dtype=_lib.DTYPE_F64 if a.dtype == "f64" else _lib.DTYPE_F32,
                           flags=0 if a.no_share else 1)
 if a.dtype == "f32":
-    cfg.update(qp_tol_comp=1e-5, qp_tol_stat=1e-4, qp_iter_max=30)
+    cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
 s = NmpcOcpSolver(cfg)
 x0 = sample_x0(B, 0, **NEAR_HOVER)
 yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4)
