@@ -177,8 +177,19 @@ def main() -> None:
         # streamed solver workspace per solve (kernel table): rows read+written per stage and IPM iteration
         ws_rows = 820 if args.no_share else 420
         ws_gbs = (n_ipm * N * ws_rows * esz) * B / kern_s / 1e9
+        # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of the SAME command
+        # (tools/rocprof_capture.sh); FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per the
+        # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
+        traffic = None
+        kname = "k_team_ipm" if args.mapping == "team" else "k_ipm"
+        pmc_file = ROOT / "profiles" / f"latest_{args.mapping}_b{B}_{args.dtype}_pmc_summary.json"
+        if pmc_file.exists() and not args.no_share and not bcast and not args.traj_out and N == 20:
+            pmc = json.loads(pmc_file.read_text()).get(kname, {})
+            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+                traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
         roof = dict(bound="hbm", kernel="k_team_ipm" if args.mapping == "team" else "k_ipm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=hbm_alg_gbs / HBM_PEAK_GBS, traffic=None,
+                    frac=hbm_alg_gbs / HBM_PEAK_GBS, traffic=traffic,
+                    traffic_source=(pmc_file.name if traffic is not None else None),
                     kernel_ms=st["ms_solve"], prepare_ms=st["ms_prepare"], algorithmic_bytes_per_solve=alg_b,
                     workspace_model_gbs=ws_gbs,
                     alu=dict(achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak,

@@ -40,8 +40,9 @@ __global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Outputs<T> o
 }
 
 // QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
-template <class T>
-__global__ __launch_bounds__(64) void k_team_ipm(Consts<T> c, Work<T> w, Outputs<T> out, TeamWork<T> tw, int B)
+// W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
+template <class T, int W>
+__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Outputs<T> out, TeamWork<T> tw, int B)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     team_ipm(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw));
@@ -69,6 +70,8 @@ struct nmpc_solver {
     // single-instance slot (AcadosOcpSolver.set/get state)
     std::vector<double> sx, su, syref, syref_e, sx0;
     bool x0_set = false;
+    int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2|4 picks the register budget variant
+    int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
 
     int fail(int code, const char *fmt, ...)
     {
@@ -190,6 +193,14 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         s->cfg.qp_iter_max = std::min(cfg->qp_iter_max, 30);
     }
     s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
+    if (const char *e = std::getenv("NMPC_TEAM_OCC")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4) s->team_occ = v;
+    }
+    if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
+        const int v = std::atoi(e);
+        if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
+    }
     s->Bp = (cfg->max_batch + 63) / 64 * 64;
     if (alloc_ws(s) != 0) {
         g_create_error = s->err;
@@ -256,8 +267,17 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         TeamWork<T> tw;
         tw.tLM = (T *)s->LM;
         tw.tIV = (T *)s->iv;
-        const dim3 tgrid((B + TEAMS_PER_WAVE - 1) / TEAMS_PER_WAVE);
-        hipLaunchKernelGGL(k_team_ipm<T>, tgrid, block, TEAMS_PER_WAVE * TEAM_LDS * sizeof(T), st, c, w, out, tw, B);
+        // teams per wave: 4 fills the lanes; fewer (half-empty waves) when the batch alone cannot
+        // put two waves on every SIMD, so that LDS/memory latency still has something to hide behind
+        int tpw = s->team_tpw;
+        if (tpw == 0) tpw = (B >= 8192) ? 4 : (B >= 4096 ? 2 : 1);
+        const dim3 tgrid((B + tpw - 1) / tpw), tblock(16 * tpw);
+        int occ = s->team_occ;
+        if (occ == 0) occ = 2;
+        const size_t lds = (size_t)tpw * TEAM_LDS * sizeof(T);
+        if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        else if (occ == 2) hipLaunchKernelGGL((k_team_ipm<T, 2>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        else hipLaunchKernelGGL((k_team_ipm<T, 4>), tgrid, tblock, lds, st, c, w, out, tw, B);
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }

@@ -38,7 +38,11 @@ constexpr int L_Y = L_D + 8;        // [2][16][4] partial products M[:,c]*x_c, d
 constexpr int L_XH = L_Y + 128;     // [2][16]
 constexpr int L_DR = L_XH + 32;     // [2][4]
 constexpr int L_RED = L_DR + 8;     // [32] small reductions
-constexpr int TEAM_LDS = L_RED + 32;   // 800 elements
+// 808 elements: as bytes (6464 B FP64 / 3232 B FP32) the team stride is 64 B resp. 160 B past a
+// multiple of the 256-B LDS bank row, so the four teams of a wave - which issue the same relative
+// address at the same time - fall on different banks.  (A stride of 800 doubles = 25 bank rows
+// made every broadcast read a 4-way conflict: SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles.)
+constexpr int TEAM_LDS = L_RED + 40;
 
 template <class T>
 struct TeamWork {
@@ -47,6 +51,18 @@ struct TeamWork {
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// Exchange point inside a stage.  The workgroup is ONE wave and a wave's LDS instructions execute
+// in issue order, so a ds_read issued after a ds_write of another lane already sees the data: no
+// s_barrier and - unlike __syncthreads() - no s_waitcnt vmcnt(0) that would drain the global
+// stores/prefetches in flight.  The builtin only pins the instruction order for the compiler.
+// Global data handed between lanes (L, m written by lane 0) crosses real __syncthreads() at the
+// sweep boundaries.
+#ifndef NMPC_TEAM_FULL_SYNC
+#define NMPC_WSYNC() __builtin_amdgcn_wave_barrier()
+#else
+#define NMPC_WSYNC() __syncthreads()
+#endif
 
 template <class T>
 __device__ __forceinline__ T sel4(const T *v, int j)
@@ -62,7 +78,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     const int rr = r < NX ? r : NX - 1;   // row used for loads; rows 13..15 shadow row 12 and never store
     const int j = r & 3;                  // input component handled by lanes r < 4 (others shadow)
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * TEAMS_PER_WAVE + team;
+    int inst = blockIdx.x * (blockDim.x >> 4) + team;   // 1, 2 or 4 teams per wave (launch decides)
     const bool valid = inst < B;
     if (!valid) inst = B - 1;             // idle teams shadow the last instance and never store
     const int N = c.N, Bp = w.Bp, lane = inst;
@@ -90,7 +106,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         }
         b_r = NMPC_LD(w.bv + k * bs_, rr);
         sbv[r] = b_r;
-        __syncthreads();
+        NMPC_WSYNC();
         const int cz = rr >= 6 ? rr - 6 : 0;
         NMPC_UNROLL for (int l = 0; l < NX; l++) {
             const T zc = sAd[l * 8 + cz];
@@ -120,6 +136,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         }
     }
     __syncthreads();
+    NMPC_PROF_BEGIN
     T mu = c.mu0, rho = T(1), alpha = 0, sigmu = 0;
     int it = 0, status = 0;
     bool pending = false, done = false;
@@ -183,7 +200,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int i = 0; i < NU; i++) sPB[r * 4 + i] = PBrow[i];
             sh[r] = h;
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) sPA[r * 14 + cc] = PArow[cc];
-            __syncthreads();
+            NMPC_WSYNC();
             // P2: lanes 0..9 one entry of Huu = D + B'PB each, lanes 10..13 one entry of gu = rhat + B'h
             {
                 const int e = r < 14 ? r : 13;
@@ -193,7 +210,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int l = 0; l < NX; l++) a += sB[l * 4 + ei] * (e < 10 ? sPB[l * 4 + ej] : sh[l]);
                 sHg[r] = a;
             }
-            __syncthreads();
+            NMPC_WSYNC();
             // P3: Cholesky (replicated), column r of M, p_k
             T Lf[10], mv[NU], Mcol[NU];
             NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
@@ -228,7 +245,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             T pvn = gx;
             NMPC_UNROLL for (int i = 0; i < NU; i++) pvn -= Mcol[i] * mv[i];
-            __syncthreads();
+            NMPC_WSYNC();
             // P4: row r of P_k = Q + A'(PA) - M'M
             if (k > 0) {
                 NMPC_UNROLL for (int cc = 0; cc < NX; cc++) {
@@ -239,8 +256,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
                 pv = pvn;
             }
-            __syncthreads();
+            NMPC_WSYNC();
         }
+        NMPC_STAMP(0)
         if (cmpl) sRed[j] = musum;
         __syncthreads();
         const T mu_now = (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / nc;
@@ -259,7 +277,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) sY[p * 64 + r * 4 + i] = lmk[rr * 4 + i] * xh;
             sXh[p * 16 + r] = xh;
-            __syncthreads();
+            NMPC_WSYNC();
             T uh[NU], Lf[10];
             NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -291,6 +309,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
+        NMPC_STAMP(1)
         if (cmpl) { sRed[4 + j] = aaff; sRed[8 + j] = s2; }
         __syncthreads();
         aaff = fmin(fmin(sRed[4], sRed[5]), fmin(sRed[6], sRed[7]));
@@ -320,7 +339,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 if (cmpl) sDr[p * 4 + j] = -(sigmu - cl) / tl + (sigmu - cu) / tu;
             }
             sXh[p * 16 + r] = pv;
-            __syncthreads();
+            NMPC_WSYNC();
             T mv[NU], Lf[10];
             NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -340,6 +359,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
+        NMPC_STAMP(2)
         __syncthreads();   // m of every stage (written by lane 0) visible to the team
 
         // ================= sweep E: forward homogeneous solve, final direction
@@ -351,7 +371,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) sY[p * 64 + r * 4 + i] = lmk[rr * 4 + i] * xh;
             sXh[p * 16 + r] = xh;
-            __syncthreads();
+            NMPC_WSYNC();
             T uh[NU], Lf[10];
             NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -385,6 +405,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
+        NMPC_STAMP(3)
         if (cmpl) sRed[12 + j] = amax;
         __syncthreads();
         amax = fmin(fmin(sRed[12], sRed[13]), fmin(sRed[14], sRed[15]));
@@ -405,6 +426,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
             ms += (ll + alpha_new * dl) * (tl + alpha_new * d) + (lu + alpha_new * du) * (tu - alpha_new * d);
         }
+        NMPC_STAMP(4)
         if (cmpl) sRed[16 + j] = ms;
         __syncthreads();
         ms = sRed[16] + sRed[17] + sRed[18] + sRed[19];
@@ -421,6 +443,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         __syncthreads();   // sRed is reused by the next iteration
     }
 
+    NMPC_STAMP(5)
     // ---- final sweep: pending update of the inputs, state rollout, full SQP step (U1)
     {
         T dx = 0;
@@ -434,7 +457,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (pending) u += alpha * ivk[16 + j];
             if (cmpl) sDr[p * 4 + j] = u;
             sXh[p * 16 + r] = dx;
-            __syncthreads();
+            NMPC_WSYNC();
             T du[NU];
             NMPC_UNROLL for (int i = 0; i < NU; i++) { du[i] = sDr[p * 4 + i]; bad |= !(du[i] == du[i]); }
             T a = b_r;
@@ -455,6 +478,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         NMPC_UNROLL for (int l = 0; l < NX; l++) nb += sXh[l];
         if (nb > T(0) && upd) status = 1;
     }
+    NMPC_STAMP(6)
+    NMPC_PROF_END(w)
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     if (valid) {
         if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; }

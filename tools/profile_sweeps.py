@@ -27,11 +27,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--no-share", action="store_true")
+ap.add_argument("--mapping", default="team")
 a = ap.parse_args()
 
 B = a.batch
 cfg = _lib.default_config(max_batch=B, dtype=_lib.DTYPE_F64 if a.dtype == "f64" else _lib.DTYPE_F32,
-                          flags=0 if a.no_share else 1)
+                          flags=(0 if a.no_share else 1) | (2 if a.mapping == 'team' else 0))
 if a.dtype == "f32":
     cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
 s = NmpcOcpSolver(cfg)
@@ -50,7 +51,8 @@ host = np.zeros((8, Bp), dtype=np.int64)
 hip = C.CDLL("libamdhip64.so")
 hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 assert hip.hipMemcpy(host.ctypes.data, dptr, host.nbytes, 2) == 0
-per_wave = host[:, :B].reshape(8, -1, 64)[:, :, 0] * 0.01   # s_memrealtime ticks at 100 MHz -> us
+grp = 64 if a.mapping == 'lane' else 4
+per_wave = host[:, :B].reshape(8, -1, grp)[:, :, 0] * 0.01   # s_memrealtime ticks at 100 MHz -> us
 names = ["A factor(bwd)", "B fwd affine", "D bwd homog", "E fwd homog", "F mu sweep", "(loop exit)", "final rollout"]
 tot = per_wave.sum(0)
 print(f"batch {B} dtype {a.dtype} share={not a.no_share}: kernel {st['ms_solve']:.3f} ms, prepare {st['ms_prepare']:.3f} ms, "
