@@ -41,11 +41,11 @@ __global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Outputs<T> o
 
 // QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
 // W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
-template <class T, int W>
+template <class T, int W, bool SHARED>
 __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Outputs<T> out, TeamWork<T> tw, int B)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    team_ipm(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw));
+    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw));
 }
 
 }  // namespace
@@ -56,7 +56,7 @@ struct nmpc_solver {
     int Bp = 0;
     size_t esz = 8;
     // device workspace (element type = cfg.dtype)
-    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr;
+    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr;
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
@@ -142,7 +142,8 @@ static int alloc_ws(nmpc_solver *s)
     struct { void **p; size_t n; } a[] = {
         {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
         {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bp * e},
-        {&s->iv, N * IV_ROWS * Bp * e}, {(void **)&s->d_iters, Bp * sizeof(int32_t)},
+        {&s->iv, N * IV_ROWS * Bp * e},
+        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bp : 1) * e}, {(void **)&s->d_iters, Bp * sizeof(int32_t)},
         {(void **)&s->d_status, Bp * sizeof(int32_t)}};
     for (auto &x : a) {
         HIP_TRY(s, hipMalloc(x.p, x.n));
@@ -195,7 +196,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
     if (const char *e = std::getenv("NMPC_TEAM_OCC")) {
         const int v = std::atoi(e);
-        if (v == 1 || v == 2 || v == 4) s->team_occ = v;
+        if (v == 1 || v == 2) s->team_occ = v;
     }
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
@@ -226,7 +227,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -252,6 +253,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     w.AB = (T *)s->AB; w.bv = (T *)s->bv; w.qr = (T *)s->qr; w.xl = (T *)s->xl; w.ul = (T *)s->ul;
     w.LM = (T *)s->LM; w.iv = (T *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
     w.prof = s->d_prof;
+    w.tAB = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? (T *)s->tAB : nullptr;
     Inputs<T> in;
     in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
     in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
@@ -270,14 +272,15 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         // teams per wave: 4 fills the lanes; fewer (half-empty waves) when the batch alone cannot
         // put two waves on every SIMD, so that LDS/memory latency still has something to hide behind
         int tpw = s->team_tpw;
-        if (tpw == 0) tpw = (B >= 8192) ? 4 : (B >= 4096 ? 2 : 1);
+        if (tpw == 0) tpw = (B >= 2048) ? 4 : (B >= 512 ? 2 : 1);   // measured: 4 is best from B = 4096 up
         const dim3 tgrid((B + tpw - 1) / tpw), tblock(16 * tpw);
         int occ = s->team_occ;
-        if (occ == 0) occ = 2;
+        if (occ == 0) occ = 1;
         const size_t lds = (size_t)tpw * TEAM_LDS * sizeof(T);
-        if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1>), tgrid, tblock, lds, st, c, w, out, tw, B);
-        else if (occ == 2) hipLaunchKernelGGL((k_team_ipm<T, 2>), tgrid, tblock, lds, st, c, w, out, tw, B);
-        else hipLaunchKernelGGL((k_team_ipm<T, 4>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, out, tw, B);
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }

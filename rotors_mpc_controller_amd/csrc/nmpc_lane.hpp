@@ -74,6 +74,7 @@ struct Work {
     T *iv;    // [N][20][Bp]
     int32_t *iters;   // [Bp]
     int32_t *status;  // [Bp]
+    T *tAB;           // [B][Ns][176] per-instance copy of (Ad rows | B rows | b) for the team kernel, or null
     long long *prof;  // [8][Bp] per-sweep time stamps, NMPC_PROFILE builds only (else null)
 };
 

@@ -5,11 +5,14 @@
 // memory-latency bound (profiles/).  Here a wave holds 4 instances; lane r of a team
 // owns ROW r of the 13x13 Riccati matrix and of the stage matrices, the replicated operands
 // (B, the 7 dense columns of A, P*A, M) are exchanged through LDS, and one wave per workgroup
-// makes every __syncthreads() a single-wave barrier.  B = 4096 -> 1024 waves = one per SIMD.
+// makes every exchange a single-wave hand-off.  B = 4096 -> 1024 waves = one per SIMD.
 //
 // Same algorithm and constants as lane_ipm() in nmpc_ipm.hpp and as the oracle; only the
 // distribution of the arithmetic over lanes differs ([UPSTREAM] HPIPM Riccati IPM, reached by
-// the reference through AcadosOcpSolver.solve(), controller.py:447).
+// the reference through AcadosOcpSolver.solve(), controller.py:447).  Two arithmetic short-cuts
+// change results at rounding level only (tests hold 1e-9 against the oracle): slack reciprocals
+// (v_rcp_f64 + 2 Newton steps) replace the ~130 IEEE divisions per stage and iteration, and the
+// Cholesky pivots use v_rsq_f64 + 2 Newton steps.
 //
 // Per-instance scratch in HBM is "array of structures" (a team reads contiguous runs):
 //   tLM [inst][stage][72] : M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | pad
@@ -24,6 +27,7 @@ namespace nmpc {
 constexpr int TEAM = 16;            // lanes per instance (one DPP row)
 constexpr int TEAMS_PER_WAVE = 4;
 constexpr int TLM_ROWS = 72;
+constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
 // LDS carve per team, in elements of T
 constexpr int L_AD = 0;             // [16][8]   rows of the dense A columns
 constexpr int L_B = L_AD + 128;     // [16][4]
@@ -38,11 +42,12 @@ constexpr int L_Y = L_D + 8;        // [2][16][4] partial products M[:,c]*x_c, d
 constexpr int L_XH = L_Y + 128;     // [2][16]
 constexpr int L_DR = L_XH + 32;     // [2][4]
 constexpr int L_RED = L_DR + 8;     // [32] small reductions
-// 808 elements: as bytes (6464 B FP64 / 3232 B FP32) the team stride is 64 B resp. 160 B past a
+constexpr int L_Z = L_RED + 32;     // [32] the 28 entries of the (q,omega)x(q,omega) block of A'PA
+// 840 elements: as bytes (6720 B FP64 / 3360 B FP32) the team stride is 64 B resp. 32 B past a
 // multiple of the 256-B LDS bank row, so the four teams of a wave - which issue the same relative
 // address at the same time - fall on different banks.  (A stride of 800 doubles = 25 bank rows
 // made every broadcast read a 4-way conflict: SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles.)
-constexpr int TEAM_LDS = L_RED + 40;
+constexpr int TEAM_LDS = L_Z + 40;
 
 template <class T>
 struct TeamWork {
@@ -64,13 +69,59 @@ struct TeamWork {
 #define NMPC_WSYNC() __syncthreads()
 #endif
 
+// hard fence for the machine scheduler: nothing is moved across it (used to keep LDS reads batched)
+#define NMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ double fast_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ float fast_rcp(float x)
+{
+    float r = __builtin_amdgcn_rcpf(x);
+    return __builtin_fmaf(__builtin_fmaf(-x, r, 1.0f), r, r);
+}
+__device__ __forceinline__ double fast_rsqrt(double x)
+{
+    double y = __builtin_amdgcn_rsq(x);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+    y = __builtin_fma(0.5 * y, __builtin_fma(-x * y, y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ float fast_rsqrt(float x)
+{
+    float y = __builtin_amdgcn_rsqf(x);
+    return __builtin_fmaf(0.5f * y, __builtin_fmaf(-x * y, y, 1.0f), y);
+}
+
 template <class T>
 __device__ __forceinline__ T sel4(const T *v, int j)
 {
     return j == 0 ? v[0] : (j == 1 ? v[1] : (j == 2 ? v[2] : v[3]));
 }
 
+// index of entry (a,b), a <= b, in the packed upper triangle of a 7x7 symmetric block
+__device__ __forceinline__ constexpr int zidx(int a, int b) { return a * 7 - a * (a - 1) / 2 + (b - a); }
+
+// slack reciprocals and affine-direction pieces of one bound pair (lower, upper) of one input
 template <class T>
+struct Pair {
+    T tl, tu, itl, itu, kl, ku;
+    __device__ __forceinline__ Pair(T u, T ll, T lu, T lo, T hi)
+    {
+        tl = u - lo; tu = hi - u;
+        itl = fast_rcp(tl); itu = fast_rcp(tu);
+        kl = ll * itl; ku = lu * itu;
+    }
+};
+
+// BATCH: read the LDS operands of the P*[B b A] products in fenced batches (1 wave per SIMD only)
+// SHARED: all stages use one (Ad, B, b) (cold start, NMPC_FLAG_SHARE_COLD_START) - compile time so
+// that the per-stage reload code and its address arithmetic do not exist in the shared variant
+template <class T, bool BATCH, bool SHARED>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
                                          const TeamWork<T> &tw, int B, T *smem)
 {
@@ -83,39 +134,51 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     if (!valid) inst = B - 1;             // idle teams shadow the last instance and never store
     const int N = c.N, Bp = w.Bp, lane = inst;
     const T nc = T(2 * NU) * T(N);
-    const size_t abs_ = c.shared ? 0 : (size_t)AB_ROWS * Bp, bs_ = c.shared ? 0 : (size_t)NX * Bp;
     T *S = smem + team * TEAM_LDS;
     T *sAd = S + L_AD, *sB = S + L_B, *sbv = S + L_BV, *sPB = S + L_PB, *sh = S + L_H, *sPA = S + L_PA;
     T *sHg = S + L_HG, *sMc = S + L_MC, *sD = S + L_D, *sY = S + L_Y, *sXh = S + L_XH, *sDr = S + L_DR;
-    T *sRed = S + L_RED;
+    T *sRed = S + L_RED, *sZ = S + L_Z;
     T *tLM = tw.tLM + (size_t)inst * N * TLM_ROWS, *tIV = tw.tIV + (size_t)inst * N * IV_ROWS;
+
+    // the two (a,b) entries of the packed 7x7 block this lane computes in the P update
+    int za0 = 0, zb0 = 0, za1 = 0, zb1 = 0;
+    {
+        const int e0 = r < 14 ? 2 * r : 26, e1 = e0 + 1;
+        NMPC_UNROLL for (int a = 0; a < NZ; a++) {
+            NMPC_UNROLL for (int b = a; b < NZ; b++) {
+                if (zidx(a, b) == e0) { za0 = a; zb0 = b; }
+                if (zidx(a, b) == e1) { za1 = a; zb1 = b; }
+            }
+        }
+    }
+    const int az = rr >= 6 ? rr - 6 : 0;   // column of the packed block this row corresponds to
 
     // row r of the stage matrices and column r of A, in registers
     T Adrow[NZ], Brow[NU], b_r = 0, Acol[NX];
+    // stage data come from the team-friendly copy written by k_prepare:
+    // tAB [inst][Ns][TAB_ROWS] = Ad rows [13][8] | B rows [13][4] | b [13]  (a lane reads 64 + 32 + 8 B)
     auto load_stage = [&](int k) {
-        const T *ABk = w.AB + k * abs_;
-        NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
-            const T v = NMPC_LD(ABk, ad_ofs(cc) + (rr < ad_rows(cc) ? rr : 0));
-            Adrow[cc] = rr < ad_rows(cc) ? v : T(0);
-            sAd[r * 8 + cc] = Adrow[cc];
+        const T *a = w.tAB + ((size_t)inst * (SHARED ? 1 : N) + k) * TAB_ROWS;
+        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) {
+            const T v = a[rr * 8 + cc];
+            if (cc < NZ) Adrow[cc] = v;
+            sAd[r * 8 + cc] = v;
         }
-        sAd[r * 8 + 7] = 0;
         NMPC_UNROLL for (int i = 0; i < NU; i++) {
-            Brow[i] = NMPC_LD(ABk, AD_SIZE + rr * NU + i);
+            Brow[i] = a[104 + rr * NU + i];
             sB[r * 4 + i] = Brow[i];
         }
-        b_r = NMPC_LD(w.bv + k * bs_, rr);
+        b_r = a[156 + rr];
         sbv[r] = b_r;
         NMPC_WSYNC();
-        const int cz = rr >= 6 ? rr - 6 : 0;
         NMPC_UNROLL for (int l = 0; l < NX; l++) {
-            const T zc = sAd[l * 8 + cz];
+            const T zc = sAd[l * 8 + az];
             const T e = (l == rr) ? T(1) : T(0);
             const T ev = (l == rr - 3) ? c.dt : T(0);
             Acol[l] = rr >= 6 ? zc : (rr >= 3 ? e + ev : e);
         }
     };
-    if (c.shared) load_stage(0);
+    if (SHARED) load_stage(0);
 
     const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
     // ---- initial point
@@ -137,14 +200,14 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     }
     __syncthreads();
     NMPC_PROF_BEGIN
-    T mu = c.mu0, rho = T(1), alpha = 0, sigmu = 0;
+    T mu = c.mu0, rho = T(1);
     int it = 0, status = 0;
-    bool pending = false, done = false;
+    bool done = false;
     const T Qdr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Qd[i] : v; return v; }();
     const T QdNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.QdN[i] : v; return v; }();
 
     for (;;) {
-        // per-team termination test; the wave keeps sweeping until all four teams are done
+        // per-team termination test; the wave keeps sweeping until all its teams are done
         if (!done) {
             if (!(mu == mu)) { status = 1; done = true; }
             else if (mu <= c.tol_comp && rho <= c.tol_stat) done = true;
@@ -155,45 +218,70 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         const bool st_ok = act && valid;
         if (act) it++;
 
-        // ================= sweep A: lazy update + backward factorisation, affine rhs
+        // ================= sweep A: backward factorisation, affine right-hand side
         T Prow[NX], pv;
         NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = (cc == rr) ? QdNr : T(0);
         pv = NMPC_LD(w.qr, N * QR_ROWS + rr);
-        bool ok = true;
-        T musum = 0;
+        bool ok = true, nanp = false;
+        // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
+        T n_ul = NMPC_LD(w.ul, (N - 1) * NU + j), n_u = tIV[(N - 1) * IV_ROWS + j],
+          n_ll = tIV[(N - 1) * IV_ROWS + 4 + j], n_lu = tIV[(N - 1) * IV_ROWS + 8 + j],
+          n_rk = NMPC_LD(w.qr, (N - 1) * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, (N - 1) * QR_ROWS + rr);
         for (int k = N - 1; k >= 0; k--) {
-            if (!c.shared) load_stage(k);
-            T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
-            {
-                const T ul = NMPC_LD(w.ul, k * NU + j);
-                const T lo = lbj - ul, hi = ubj - ul;
-                T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
-                if (pending) {
-                    const T tl = u - lo, tu = hi - u;
-                    const T da = ivk[12 + j] - u, d = ivk[16 + j];
-                    const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                    const T cl = dla * da, cu = -dua * da;
-                    const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                    const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
-                    if (cmpl && st_ok) { ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu; }
-                }
-                const T tl = u - lo, tu = hi - u;
-                musum += ll * tl + lu * tu;
-                const T sg = ll / tl + lu / tu;
-                if (cmpl) { sD[j] = Rdj + sg; sD[4 + j] = NMPC_LD(w.qr, k * QR_ROWS + NX + j) - sg * u; }
+            if (!SHARED) load_stage(k);
+            T *lmk = tLM + k * TLM_ROWS;
+            const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr;
+            if (k > 0) {
+                const T *ivn = tIV + (k - 1) * IV_ROWS;
+                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j];
+                n_rk = NMPC_LD(w.qr, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_LD(w.qr, (k - 1) * QR_ROWS + rr);
             }
-            const T q_r = NMPC_LD(w.qr, k * QR_ROWS + rr);
-            // P1: row r of P*B, P*b + p, P*A
+            {
+                const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
+                const T sg = pr.kl + pr.ku;
+                if (cmpl) { sD[j] = Rdj + sg; sD[4 + j] = rk - sg * u; }
+            }
+            // P1: row r of P*B, P*b + p, P*A.  The LDS operands are read in three batches with the
+            // scheduler fenced in between: left alone, hipcc interleaves "one ds_read, wait, two
+            // FMAs" and exposes the full LDS latency on every read (one wave per SIMD: nothing
+            // else to run).  Batched, 30-odd reads are in flight and the counted lgkmcnt waits
+            // consume them in order.
             T PBrow[NU], h = pv, PArow[NX];
             NMPC_UNROLL for (int i = 0; i < NU; i++) PBrow[i] = 0;
             NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) PArow[6 + cc] = 0;
-            NMPC_UNROLL for (int l = 0; l < NX; l++) {
-                const T pl = Prow[l];
-                NMPC_UNROLL for (int i = 0; i < NU; i++) PBrow[i] += pl * sB[l * 4 + i];
-                h += pl * sbv[l];
-                NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
-                    if (l < ad_rows(cc)) PArow[6 + cc] += pl * sAd[l * 8 + cc];
+            if (!BATCH) {   // several waves per SIMD hide the latency; keep the register footprint small
+                NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                    const T pl = Prow[l];
+                    NMPC_UNROLL for (int i = 0; i < NU; i++) PBrow[i] += pl * sB[l * 4 + i];
+                    h += pl * sbv[l];
+                    NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
+                        if (l < ad_rows(cc)) PArow[6 + cc] += pl * sAd[l * 8 + cc];
+                    }
+                }
+            } else {
+                T Bl[NX][NU], bl[NX];
+                NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                    NMPC_UNROLL for (int i = 0; i < NU; i++) Bl[l][i] = sB[l * 4 + i];
+                    bl[l] = sbv[l];
+                }
+                NMPC_SCHED_FENCE();
+                NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                    NMPC_UNROLL for (int i = 0; i < NU; i++) PBrow[i] += Prow[l] * Bl[l][i];
+                    h += Prow[l] * bl[l];
+                }
+            }
+            if (BATCH) NMPC_UNROLL for (int half = 0; half < 2; half++) {
+                const int l0 = half ? 7 : 0, l1 = half ? NX : 7;
+                T Al[7][8];
+                NMPC_SCHED_FENCE();
+                NMPC_UNROLL for (int l = l0; l < l1; l++) {
+                    NMPC_UNROLL for (int cc = 0; cc < 8; cc++) Al[l - l0][cc] = sAd[l * 8 + cc];
+                }
+                NMPC_SCHED_FENCE();
+                NMPC_UNROLL for (int l = l0; l < l1; l++) {
+                    NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
+                        if (l < ad_rows(cc)) PArow[6 + cc] += Prow[l] * Al[l - l0][cc];
+                    }
                 }
             }
             NMPC_UNROLL for (int i = 0; i < 3; i++) { PArow[i] = Prow[i]; PArow[3 + i] = c.dt * Prow[i] + Prow[3 + i]; }
@@ -207,8 +295,19 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const int ei = e < 10 ? (e >= 6 ? 3 : (e >= 3 ? 2 : (e >= 1 ? 1 : 0))) : e - 10;
                 const int ej = e < 10 ? e - ei * (ei + 1) / 2 : 0;
                 T a = e < 10 ? (ei == ej ? sD[ei] : T(0)) : sD[4 + ei];
-                NMPC_UNROLL for (int l = 0; l < NX; l++) a += sB[l * 4 + ei] * (e < 10 ? sPB[l * 4 + ej] : sh[l]);
+                const T *rhs = e < 10 ? sPB + ej : sh;
+                const int rst = e < 10 ? 4 : 1;
+                NMPC_UNROLL for (int l = 0; l < NX; l++) a += sB[l * 4 + ei] * rhs[l * rst];
                 sHg[r] = a;
+            }
+            // the two (z,z) dot products of A'(PA) owned by this lane (independent of P2/P3)
+            if (k > 0) {
+                T d0 = 0, d1 = 0;
+                NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                    d0 += sAd[l * 8 + za0] * sPA[l * 14 + 6 + zb0];
+                    d1 += sAd[l * 8 + za1] * sPA[l * 14 + 6 + zb1];
+                }
+                if (r < 14) { sZ[2 * r] = d0; sZ[2 * r + 1] = d1; }
             }
             NMPC_WSYNC();
             // P3: Cholesky (replicated), column r of M, p_k
@@ -218,8 +317,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
                 T d = Lf[lidx(jj, jj)];
                 NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
-                if (!(d > T(0))) { ok = false; d = T(1); }
-                const T rd = nmpc_rsqrt(d);
+                if (!(d > T(0))) { ok = false; nanp |= !(d == d); d = T(1); }
+                const T rd = fast_rsqrt(d);
                 Lf[lidx(jj, jj)] = rd;
                 NMPC_UNROLL for (int i = jj + 1; i < NU; i++) {
                     T a = Lf[lidx(i, jj)];
@@ -246,11 +345,28 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T pvn = gx;
             NMPC_UNROLL for (int i = 0; i < NU; i++) pvn -= Mcol[i] * mv[i];
             NMPC_WSYNC();
-            // P4: row r of P_k = Q + A'(PA) - M'M
+            // P4: row r of P_k = Q + A'(PA) - M'M.  A = [I dt*I X; 0 I Y; 0 0 Z]: position rows of
+            // A'(PA) are rows of PA, velocity rows add dt times the position row, and the (q,omega)
+            // rows are the transposed (p,v)x(q,omega) entries plus the 28 dot products in sZ.
             if (k > 0) {
+                T Pn[NX];
+                if (rr < 3) {
+                    NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Pn[cc] = PArow[cc];
+                } else if (rr < 6) {
+                    NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Pn[cc] = PArow[cc] + c.dt * sPA[(rr - 3) * 14 + cc];
+                } else {
+                    NMPC_UNROLL for (int cc = 0; cc < 3; cc++) {
+                        const T tp = sPA[cc * 14 + 6 + az];
+                        Pn[cc] = tp;
+                        Pn[3 + cc] = sPA[(3 + cc) * 14 + 6 + az] + c.dt * tp;
+                    }
+                    NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
+                        const int lo_ = az < cc ? az : cc, hi_ = az < cc ? cc : az;
+                        Pn[6 + cc] = sZ[lo_ * 7 - lo_ * (lo_ - 1) / 2 + (hi_ - lo_)];
+                    }
+                }
                 NMPC_UNROLL for (int cc = 0; cc < NX; cc++) {
-                    T a = (cc == rr) ? Qdr : T(0);
-                    NMPC_UNROLL for (int l = 0; l < NX; l++) a += Acol[l] * sPA[l * 14 + cc];
+                    T a = Pn[cc] + ((cc == rr) ? Qdr : T(0));
                     NMPC_UNROLL for (int i = 0; i < NU; i++) a -= Mcol[i] * sMc[cc * 4 + i];
                     Prow[cc] = a;
                 }
@@ -259,45 +375,46 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_WSYNC();
         }
         NMPC_STAMP(0)
-        if (cmpl) sRed[j] = musum;
-        __syncthreads();
-        const T mu_now = (sRed[0] + sRed[1] + sRed[2] + sRed[3]) / nc;
-        if (act) {
-            pending = false;
-            mu = mu_now;
-            if (!ok) { status = (mu == mu) ? 4 : 1; done = true; }
-        }
+        __syncthreads();   // L, m of every stage (written by lane 0) visible to the team
+        if (act && !ok) { status = nanp ? 1 : 4; done = true; }
         const bool act2 = act && !done, st_ok2 = act2 && valid;
 
         // ================= sweep B: forward affine solve
-        T xh = 0, aaff = T(1), s2 = 0;
+        T xh = 0, rmax = T(1), s2 = 0;   // rmax: largest inverse step length, floor 1 => alpha_aff <= 1
         int p = 0;
+        T nM[NU], nLf[10], nm[NU], n_uu, n_l2, n_l3;
+        auto prefetch_fwd = [&](int k) {
+            const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+            NMPC_UNROLL for (int i = 0; i < NU; i++) { nM[i] = lmn[rr * 4 + i]; nm[i] = lmn[62 + i]; }
+            NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
+            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j];
+        };
+        prefetch_fwd(0);
         for (int k = 0; k < N; k++) {
-            if (!c.shared) load_stage(k);
-            T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
-            NMPC_UNROLL for (int i = 0; i < NU; i++) sY[p * 64 + r * 4 + i] = lmk[rr * 4 + i] * xh;
+            if (!SHARED) load_stage(k);
+            T *ivk = tIV + k * IV_ROWS;
+            T Lf[10], uh[NU];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) { sY[p * 64 + r * 4 + i] = nM[i] * xh; uh[i] = nm[i]; }
+            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = nLf[i];
+            const T ul = n_ul, u = n_uu, ll = n_l2, lu = n_l3;
             sXh[p * 16 + r] = xh;
+            if (k + 1 < N) prefetch_fwd(k + 1);
             NMPC_WSYNC();
-            T uh[NU], Lf[10];
-            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                T a = lmk[62 + i];
+                T a = uh[i];
                 NMPC_UNROLL for (int cc = 0; cc < NX; cc++) a += sY[p * 64 + cc * 4 + i];
                 uh[i] = -a;
             }
             lt_solve(Lf, uh);
             {
-                const T ul = NMPC_LD(w.ul, k * NU + j);
-                const T lo = lbj - ul, hi = ubj - ul;
-                const T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
+                const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
                 const T uj = sel4(uh, j);
                 if (cmpl && st_ok2) ivk[12 + j] = uj;
-                const T tl = u - lo, tu = hi - u, d = uj - u;
-                const T dla = -ll - ll / tl * d, dua = -lu + lu / tu * d;
-                if (d < T(0) && -tl / d < aaff) aaff = -tl / d;
-                if (d > T(0) && tu / d < aaff) aaff = tu / d;
-                if (dla < T(0) && -ll / dla < aaff) aaff = -ll / dla;
-                if (dua < T(0) && -lu / dua < aaff) aaff = -lu / dua;
+                const T d = uj - u;
+                const T dla = -ll - pr.kl * d, dua = -lu + pr.ku * d;
+                // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
+                const T a1 = d * pr.itl, a2 = d * pr.itu;
+                rmax = fmax(rmax, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
                 s2 += dla * d - dua * d;
             }
             if (k < N - 1) {
@@ -310,38 +427,48 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             p ^= 1;
         }
         NMPC_STAMP(1)
-        if (cmpl) { sRed[4 + j] = aaff; sRed[8 + j] = s2; }
+        if (cmpl) { sRed[4 + j] = rmax; sRed[8 + j] = s2; }
         __syncthreads();
-        aaff = fmin(fmin(sRed[4], sRed[5]), fmin(sRed[6], sRed[7]));
+        rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
         s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
-        T sigmu_new;
+        T sigmu;
         {
+            const T aaff = T(1) / rmax;
             const T muaff = (T(1) - aaff) * mu + aaff * aaff * s2 / nc;
             T sg3 = muaff / mu;
             sg3 = sg3 * sg3 * sg3;
-            sigmu_new = sg3 * mu;
+            sigmu = sg3 * mu;
         }
-        if (act2) sigmu = sigmu_new;
 
         // ================= sweep D: backward homogeneous solve
         pv = 0;
         p = 0;
+        T n_ua;
+        auto prefetch_bwd = [&](int k) {
+            const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+            NMPC_UNROLL for (int i = 0; i < NU; i++) nM[i] = lmn[rr * 4 + i];
+            NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
+            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_ua = ivn[12 + j];
+        };
+        prefetch_bwd(N - 1);
         for (int k = N - 1; k >= 0; k--) {
-            if (!c.shared) load_stage(k);
-            T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
+            if (!SHARED) load_stage(k);
+            T *lmk = tLM + k * TLM_ROWS;
+            T Lf[10], Mc[NU];
+            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = nLf[i];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) Mc[i] = nM[i];
             {
-                const T ul = NMPC_LD(w.ul, k * NU + j);
-                const T lo = lbj - ul, hi = ubj - ul;
-                const T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
-                const T tl = u - lo, tu = hi - u, da = ivk[12 + j] - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                const T u = n_uu, ll = n_l2, lu = n_l3;
+                const Pair<T> pr(u, ll, lu, lbj - n_ul, ubj - n_ul);
+                const T da = n_ua - u;
+                const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
                 const T cl = dla * da, cu = -dua * da;
-                if (cmpl) sDr[p * 4 + j] = -(sigmu - cl) / tl + (sigmu - cu) / tu;
+                if (cmpl) sDr[p * 4 + j] = -(sigmu - cl) * pr.itl + (sigmu - cu) * pr.itu;
             }
             sXh[p * 16 + r] = pv;
+            if (k > 0) prefetch_bwd(k - 1);
             NMPC_WSYNC();
-            T mv[NU], Lf[10];
-            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
+            T mv[NU];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
                 T a = sDr[p * 4 + i];
                 NMPC_UNROLL for (int l = 0; l < NX; l++) a += sB[l * 4 + i] * sXh[p * 16 + l];
@@ -354,7 +481,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (k > 0) {
                 T a = 0;
                 NMPC_UNROLL for (int l = 0; l < NX; l++) a += Acol[l] * sXh[p * 16 + l];
-                NMPC_UNROLL for (int i = 0; i < NU; i++) a -= lmk[rr * 4 + i] * mv[i];
+                NMPC_UNROLL for (int i = 0; i < NU; i++) a -= Mc[i] * mv[i];
                 pv = a;
             }
             p ^= 1;
@@ -362,39 +489,42 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         NMPC_STAMP(2)
         __syncthreads();   // m of every stage (written by lane 0) visible to the team
 
-        // ================= sweep E: forward homogeneous solve, final direction
+        // ================= sweep E: forward homogeneous solve, final direction, step length
         xh = 0;
         p = 0;
-        T amax = T(1e30);
+        rmax = c.tau;      // alpha = min(1, tau / max inverse step) = tau / max(rmax, tau)
+        auto prefetch_fwd2 = [&](int k) {
+            prefetch_fwd(k);
+            n_ua = tIV[k * IV_ROWS + 12 + j];
+        };
+        prefetch_fwd2(0);
         for (int k = 0; k < N; k++) {
-            if (!c.shared) load_stage(k);
-            T *ivk = tIV + k * IV_ROWS, *lmk = tLM + k * TLM_ROWS;
-            NMPC_UNROLL for (int i = 0; i < NU; i++) sY[p * 64 + r * 4 + i] = lmk[rr * 4 + i] * xh;
+            if (!SHARED) load_stage(k);
+            T *ivk = tIV + k * IV_ROWS;
+            T Lf[10], uh[NU];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) { sY[p * 64 + r * 4 + i] = nM[i] * xh; uh[i] = nm[i]; }
+            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = nLf[i];
+            const T ul = n_ul, u = n_uu, ll = n_l2, lu = n_l3, ua = n_ua;
             sXh[p * 16 + r] = xh;
+            if (k + 1 < N) prefetch_fwd2(k + 1);
             NMPC_WSYNC();
-            T uh[NU], Lf[10];
-            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = lmk[52 + i];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                T a = lmk[62 + i];
+                T a = uh[i];
                 NMPC_UNROLL for (int cc = 0; cc < NX; cc++) a += sY[p * 64 + cc * 4 + i];
                 uh[i] = -a;
             }
             lt_solve(Lf, uh);
             {
-                const T ul = NMPC_LD(w.ul, k * NU + j);
-                const T lo = lbj - ul, hi = ubj - ul;
-                const T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
-                const T tl = u - lo, tu = hi - u, da = ivk[12 + j] - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+                const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
+                const T da = ua - u;
+                const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
                 const T cl = dla * da, cu = -dua * da;
                 const T d = da + sel4(uh, j);
                 if (cmpl && st_ok2) ivk[16 + j] = d;
-                const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                if (d < T(0) && -tl / d < amax) amax = -tl / d;
-                if (d > T(0) && tu / d < amax) amax = tu / d;
-                if (dl < T(0) && -ll / dl < amax) amax = -ll / dl;
-                if (du < T(0) && -lu / du < amax) amax = -lu / du;
+                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                rmax = fmax(rmax, fmax(-d * pr.itl, d * pr.itu));
+                rmax = fmax(rmax, fmax(-dl * fast_rcp(ll), -du * fast_rcp(lu)));
             }
             if (k < N - 1) {
                 T a = 0;
@@ -406,36 +536,35 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             p ^= 1;
         }
         NMPC_STAMP(3)
-        if (cmpl) sRed[12 + j] = amax;
+        if (cmpl) sRed[12 + j] = rmax;
         __syncthreads();
-        amax = fmin(fmin(sRed[12], sRed[13]), fmin(sRed[14], sRed[15]));
-        T alpha_new = c.tau * amax;
-        if (alpha_new > T(1)) alpha_new = T(1);
-        // ================= duality measure after the step (termination test only)
+        rmax = fmax(fmax(sRed[12], sRed[13]), fmax(sRed[14], sRed[15]));
+        const T alpha = c.tau / rmax;
+        // ================= sweep F: primal-dual update, duality measure of the new iterate
         T ms = 0;
         for (int k = 0; k < N; k++) {
             T *ivk = tIV + k * IV_ROWS;
             const T ul = NMPC_LD(w.ul, k * NU + j);
+            T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
             const T lo = lbj - ul, hi = ubj - ul;
-            const T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
-            const T tl = u - lo, tu = hi - u;
+            const Pair<T> pr(u, ll, lu, lo, hi);
             const T da = ivk[12 + j] - u, d = ivk[16 + j];
-            const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
+            const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
             const T cl = dla * da, cu = -dua * da;
-            const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-            const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-            ms += (ll + alpha_new * dl) * (tl + alpha_new * d) + (lu + alpha_new * du) * (tu - alpha_new * d);
+            const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+            const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+            u += alpha * d; ll += alpha * dl; lu += alpha * du;
+            if (cmpl && st_ok2) { ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu; }
+            ms += ll * (u - lo) + lu * (hi - u);
         }
         NMPC_STAMP(4)
         if (cmpl) sRed[16 + j] = ms;
         __syncthreads();
         ms = sRed[16] + sRed[17] + sRed[18] + sRed[19];
         if (act2) {
-            alpha = alpha_new;
             if (!(alpha == alpha)) { status = 1; done = true; }
             else if (alpha < T(1e-12)) { status = 3; done = true; }
             else {
-                pending = true;
                 rho *= (T(1) - alpha);
                 mu = ms / nc;
             }
@@ -444,17 +573,15 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     }
 
     NMPC_STAMP(5)
-    // ---- final sweep: pending update of the inputs, state rollout, full SQP step (U1)
+    // ---- final sweep: state rollout from the inputs, full SQP step (U1)
     {
         T dx = 0;
         bool bad = false;
         int p = 0;
         const bool upd = (status == 0 || status == 2);
         for (int k = 0; k < N; k++) {
-            if (!c.shared) load_stage(k);
-            T *ivk = tIV + k * IV_ROWS;
-            T u = ivk[j];
-            if (pending) u += alpha * ivk[16 + j];
+            if (!SHARED) load_stage(k);
+            const T u = tIV[k * IV_ROWS + j];
             if (cmpl) sDr[p * 4 + j] = u;
             sXh[p * 16 + r] = dx;
             NMPC_WSYNC();
