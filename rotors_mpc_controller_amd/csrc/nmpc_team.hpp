@@ -289,25 +289,32 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             sh[r] = h;
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) sPA[r * 14 + cc] = PArow[cc];
             NMPC_WSYNC();
-            // P2: lanes 0..9 one entry of Huu = D + B'PB each, lanes 10..13 one entry of gu = rhat + B'h
+            // P2: lanes 0..9 one entry of Huu = D + B'PB each, lanes 10..13 one entry of gu = rhat + B'h;
+            // plus the two (z,z) dot products of A'(PA) owned by this lane.  All LDS operands first.
             {
                 const int e = r < 14 ? r : 13;
                 const int ei = e < 10 ? (e >= 6 ? 3 : (e >= 3 ? 2 : (e >= 1 ? 1 : 0))) : e - 10;
                 const int ej = e < 10 ? e - ei * (ei + 1) / 2 : 0;
-                T a = e < 10 ? (ei == ej ? sD[ei] : T(0)) : sD[4 + ei];
                 const T *rhs = e < 10 ? sPB + ej : sh;
                 const int rst = e < 10 ? 4 : 1;
-                NMPC_UNROLL for (int l = 0; l < NX; l++) a += sB[l * 4 + ei] * rhs[l * rst];
-                sHg[r] = a;
-            }
-            // the two (z,z) dot products of A'(PA) owned by this lane (independent of P2/P3)
-            if (k > 0) {
-                T d0 = 0, d1 = 0;
-                NMPC_UNROLL for (int l = 0; l < NX; l++) {
-                    d0 += sAd[l * 8 + za0] * sPA[l * 14 + 6 + zb0];
-                    d1 += sAd[l * 8 + za1] * sPA[l * 14 + 6 + zb1];
+                T xa[NX], xb[NX], a0[NX], t0[NX], a1[NX], t1[NX];
+                if (BATCH) NMPC_SCHED_FENCE();
+                NMPC_UNROLL for (int l = 0; l < NX; l++) { xa[l] = sB[l * 4 + ei]; xb[l] = rhs[l * rst]; }
+                if (k > 0) {
+                    NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                        a0[l] = sAd[l * 8 + za0]; t0[l] = sPA[l * 14 + 6 + zb0];
+                        a1[l] = sAd[l * 8 + za1]; t1[l] = sPA[l * 14 + 6 + zb1];
+                    }
                 }
-                if (r < 14) { sZ[2 * r] = d0; sZ[2 * r + 1] = d1; }
+                T a = e < 10 ? (ei == ej ? sD[ei] : T(0)) : sD[4 + ei];
+                if (BATCH) NMPC_SCHED_FENCE();
+                NMPC_UNROLL for (int l = 0; l < NX; l++) a += xa[l] * xb[l];
+                sHg[r] = a;
+                if (k > 0) {
+                    T d0 = 0, d1 = 0;
+                    NMPC_UNROLL for (int l = 0; l < NX; l++) { d0 += a0[l] * t0[l]; d1 += a1[l] * t1[l]; }
+                    if (r < 14) { sZ[2 * r] = d0; sZ[2 * r + 1] = d1; }
+                }
             }
             NMPC_WSYNC();
             // P3: Cholesky (replicated), column r of M, p_k
@@ -317,7 +324,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
                 T d = Lf[lidx(jj, jj)];
                 NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
-                if (!(d > T(0))) { ok = false; nanp |= !(d == d); d = T(1); }
+                const bool pos = d > T(0);     // branch-free: keeps the stage body one basic block
+                ok &= pos; nanp |= !(d == d); d = pos ? d : T(1);
                 const T rd = fast_rsqrt(d);
                 Lf[lidx(jj, jj)] = rd;
                 NMPC_UNROLL for (int i = jj + 1; i < NU; i++) {
