@@ -146,6 +146,32 @@ int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out);
 /* message of the last failing call on this handle (s == NULL: of the last failed create) */
 const char *nmpc_last_error(const nmpc_solver *s);
 
+/* ---- the steps either side of the solve, on the device; pointers are DEVICE pointers of
+ * element type cfg.dtype, work is enqueued on `hip_stream` ------------------------------------- */
+
+/* replaces ReferenceGenerator.build_horizon (reference.py:75-91) + the yref stacking of
+ * controller.py:433-445 for B constant setpoints: positions [B][3], yaws [B] (quaternion from yaw as
+ * reference.py:11-13), thrust reference per motor -> yref [B][N][17], yref_e [B][13]             */
+int nmpc_build_hover_reference_device(nmpc_solver *s, int B, const void *positions, const void *yaws,
+                                      double thrust_per_motor, void *yref, void *yref_e, void *hip_stream);
+
+/* replaces MPCControllerNode._odom_cb (nodes/mpc_controller_node:88-113): pose [B][7] = position(3),
+ * orientation (x,y,z,w); twist [B][6] = body-frame linear(3), angular(3) -> x0 [B][13]            */
+int nmpc_odometry_to_state_device(nmpc_solver *s, int B, const void *pose, const void *twist, void *x0,
+                                  void *hip_stream);
+
+/* replaces MPCControllerNode._publish_command (nodes/mpc_controller_node:152-164): u [B][4] thrusts ->
+ * motor speeds [B][4] (rad/s); `clipped` [B][4] (nullable) receives the bound-clipped thrusts      */
+int nmpc_commands_to_motor_speeds_device(nmpc_solver *s, int B, const void *u, double rotor_force_constant,
+                                         double motor_min_speed, double motor_max_speed, void *speeds,
+                                         void *clipped, void *hip_stream);
+
+/* plant step of a closed-loop rollout: x [B][13], u [B][4] -> x_next [B][13] with the
+ * controller's own model and ERK scheme (controller.py:183-188,267-355) over one interval dt;
+ * normalize_q != 0 renormalises the quaternion as controller.py:406-409 does on every tick          */
+int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next,
+                           int normalize_q, void *hip_stream);
+
 const char *nmpc_version(void);
 
 #ifdef __cplusplus

@@ -65,13 +65,14 @@ class NmpcStats(C.Structure):
 EXPORTS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
     "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_get_stats",
-    "nmpc_last_error", "nmpc_version",
+    "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
+    "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
 )
 
 
 def build(force: bool = False) -> Path:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_consts.hpp")]
+    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
     srcs.append(_PKG.parent / "include" / "rotors_nmpc.h")
     stale = (not LIB_PATH.exists()) or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
@@ -126,6 +127,14 @@ def load() -> C.CDLL:
     lib.nmpc_get_stats.restype = C.c_int
     lib.nmpc_last_error.argtypes = [vp]
     lib.nmpc_last_error.restype = C.c_char_p
+    lib.nmpc_build_hover_reference_device.argtypes = [vp, C.c_int, vp, vp, C.c_double, vp, vp, vp]
+    lib.nmpc_build_hover_reference_device.restype = C.c_int
+    lib.nmpc_odometry_to_state_device.argtypes = [vp, C.c_int, vp, vp, vp, vp]
+    lib.nmpc_odometry_to_state_device.restype = C.c_int
+    lib.nmpc_commands_to_motor_speeds_device.argtypes = [vp, C.c_int, vp, C.c_double, C.c_double, C.c_double, vp, vp, vp]
+    lib.nmpc_commands_to_motor_speeds_device.restype = C.c_int
+    lib.nmpc_plant_step_device.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp]
+    lib.nmpc_plant_step_device.restype = C.c_int
     lib.nmpc_version.argtypes = []
     lib.nmpc_version.restype = C.c_char_p
     _lib = lib

@@ -17,6 +17,7 @@
 #include "../../include/rotors_nmpc.h"
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
+#include "nmpc_aux.hpp"
 #include "nmpc_consts.hpp"
 
 using namespace nmpc;
@@ -459,6 +460,87 @@ int nmpc_solve(nmpc_solver *s)
     if (rc) return rc;
     if (st == 0) { s->sx = xo; s->su = uo; }
     return (int)st;
+}
+
+int nmpc_build_hover_reference_device(nmpc_solver *s, int B, const void *positions, const void *yaws,
+                                      double thrust_per_motor, void *yref, void *yref_e, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !positions || !yaws || !yref || !yref_e) return s->fail(NMPC_EARG, "build_hover_reference: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int N = s->cfg.N;
+    const size_t n = (size_t)B * N * 17 + (size_t)B * 13;
+    const dim3 grid((unsigned)std::min<size_t>((n + 255) / 256, 8192)), block(256);
+    if (s->cfg.dtype == NMPC_DTYPE_F64)
+        hipLaunchKernelGGL(k_hover_reference<double>, grid, block, 0, st, B, N, (const double *)positions,
+                           (const double *)yaws, thrust_per_motor, (double *)yref, (double *)yref_e);
+    else
+        hipLaunchKernelGGL(k_hover_reference<float>, grid, block, 0, st, B, N, (const float *)positions,
+                           (const float *)yaws, (float)thrust_per_motor, (float *)yref, (float *)yref_e);
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+int nmpc_odometry_to_state_device(nmpc_solver *s, int B, const void *pose, const void *twist, void *x0,
+                                  void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !pose || !twist || !x0) return s->fail(NMPC_EARG, "odometry_to_state: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const dim3 grid((B + 255) / 256), block(256);
+    if (s->cfg.dtype == NMPC_DTYPE_F64)
+        hipLaunchKernelGGL(k_odometry_to_state<double>, grid, block, 0, st, B, (const double *)pose, (const double *)twist, (double *)x0);
+    else
+        hipLaunchKernelGGL(k_odometry_to_state<float>, grid, block, 0, st, B, (const float *)pose, (const float *)twist, (float *)x0);
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+int nmpc_commands_to_motor_speeds_device(nmpc_solver *s, int B, const void *u, double kf, double w_min,
+                                         double w_max, void *speeds, void *clipped, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !u || !speeds) return s->fail(NMPC_EARG, "commands_to_motor_speeds: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int n = B * NU;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Bounds4<double> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = s->cfg.lbu[i]; bd.ub[i] = s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_motor_speeds<double>, grid, block, 0, st, n, (const double *)u, bd, kf, w_min, w_max,
+                           (double *)speeds, (double *)clipped);
+    } else {
+        Bounds4<float> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = (float)s->cfg.lbu[i]; bd.ub[i] = (float)s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_motor_speeds<float>, grid, block, 0, st, n, (const float *)u, bd, (float)kf, (float)w_min,
+                           (float)w_max, (float *)speeds, (float *)clipped);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next, int normalize_q,
+                           void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !x || !u || !x_next) return s->fail(NMPC_EARG, "plant_step: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const dim3 grid((B + 63) / 64), block(64);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Consts<double> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_plant_step<double>, grid, block, 0, st, c, B, (const double *)x, (const double *)u, (double *)x_next, normalize_q);
+    } else {
+        Consts<float> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_plant_step<float>, grid, block, 0, st, c, B, (const float *)x, (const float *)u, (float *)x_next, normalize_q);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
 }
 
 const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : nullptr; }

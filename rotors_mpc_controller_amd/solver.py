@@ -118,6 +118,33 @@ class NmpcOcpSolver:
                                                stream or None)
         self._check(rc)
 
+    # -- the steps either side of the solve, on the device ---------------------------
+    def build_hover_reference_device(self, B: int, positions_ptr: int, yaws_ptr: int, thrust_per_motor: float,
+                                     yref_ptr: int, yref_e_ptr: int, stream: int = 0) -> None:
+        """reference.py:75-91 + controller.py:433-445 for B constant setpoints, written in HBM."""
+        self._check(self._lib.nmpc_build_hover_reference_device(self._h, int(B), positions_ptr, yaws_ptr,
+                                                                float(thrust_per_motor), yref_ptr, yref_e_ptr,
+                                                                stream or None))
+
+    def odometry_to_state_device(self, B: int, pose_ptr: int, twist_ptr: int, x0_ptr: int, stream: int = 0) -> None:
+        """nodes/mpc_controller_node:88-113 batched: pose [B,7] (p, q=(x,y,z,w)), body twist [B,6] -> x0 [B,13]."""
+        self._check(self._lib.nmpc_odometry_to_state_device(self._h, int(B), pose_ptr, twist_ptr, x0_ptr,
+                                                            stream or None))
+
+    def commands_to_motor_speeds_device(self, B: int, u_ptr: int, rotor_force_constant: float, motor_min_speed: float,
+                                        motor_max_speed: float, speeds_ptr: int, clipped_ptr: int = 0,
+                                        stream: int = 0) -> None:
+        """nodes/mpc_controller_node:152-164 batched: thrusts [B,4] -> motor speeds [B,4]."""
+        self._check(self._lib.nmpc_commands_to_motor_speeds_device(
+            self._h, int(B), u_ptr, float(rotor_force_constant), float(motor_min_speed), float(motor_max_speed),
+            speeds_ptr, clipped_ptr or None, stream or None))
+
+    def plant_step_device(self, B: int, x_ptr: int, u_ptr: int, x_next_ptr: int, normalize_q: bool = True,
+                          stream: int = 0) -> None:
+        """One interval of the controller's own model/ERK as the plant of a closed-loop rollout."""
+        self._check(self._lib.nmpc_plant_step_device(self._h, int(B), x_ptr, u_ptr, x_next_ptr, int(normalize_q),
+                                                     stream or None))
+
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 
