@@ -43,6 +43,9 @@ extern "C" {
 
 /* flags */
 #define NMPC_FLAG_SHARE_COLD_START 1u /* cold start: all stages share one (A,B,b); linearise once */
+#define NMPC_FLAG_CONDENSED_QP 4u     /* QP phase as acados configures HPIPM for this reference: partial
+                                         condensing to qp_cond_N blocks (controller.py:181,184) + IPM on the
+                                         condensed QP.  Same solution (U8); fidelity / cross-check path, slow */
 #define NMPC_FLAG_TEAM_MAPPING 2u     /* QP phase: 16 lanes cooperate on one instance (small batches)
                                          instead of one instance per lane (large batches) */
 

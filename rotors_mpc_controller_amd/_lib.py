@@ -15,6 +15,7 @@ NX, NU, NY = 13, 4, 17
 DTYPE_F64, DTYPE_F32 = 0, 1
 FLAG_SHARE_COLD_START = 1
 FLAG_TEAM_MAPPING = 2
+FLAG_CONDENSED_QP = 4
 
 STATUS_NAMES = {0: "SUCCESS", 1: "NAN_DETECTED", 2: "MAXITER", 3: "MINSTEP", 4: "QP_FAILURE"}
 
@@ -72,7 +73,7 @@ EXPORTS = (
 
 def build(force: bool = False) -> Path:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
+    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_cond.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
     srcs.append(_PKG.parent / "include" / "rotors_nmpc.h")
     stale = (not LIB_PATH.exists()) or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:

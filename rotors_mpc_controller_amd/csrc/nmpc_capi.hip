@@ -17,6 +17,7 @@
 #include "../../include/rotors_nmpc.h"
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
+#include "nmpc_cond.hpp"
 #include "nmpc_aux.hpp"
 #include "nmpc_consts.hpp"
 
@@ -40,6 +41,14 @@ __global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Outputs<T> o
     if (lane < B) lane_ipm(c, w, out, lane);
 }
 
+// QP phase as acados configures it: partial condensing + IPM on the condensed QP (one instance per lane)
+template <class T>
+__global__ __launch_bounds__(64) void k_cond_ipm(Consts<T> c, Work<T> w, CondWork<T> cw, Outputs<T> out, int B)
+{
+    const int lane = blockIdx.x * blockDim.x + threadIdx.x;
+    if (lane < B) lane_cond_ipm(c, w, cw, out, lane);
+}
+
 // QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
 // W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
 template <class T, int W, bool SHARED>
@@ -57,7 +66,7 @@ struct nmpc_solver {
     int Bp = 0;
     size_t esz = 8;
     // device workspace (element type = cfg.dtype)
-    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr;
+    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr;
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
@@ -150,6 +159,13 @@ static int alloc_ws(nmpc_solver *s)
         HIP_TRY(s, hipMalloc(x.p, x.n));
         s->ws_bytes += x.n;
     }
+    if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
+        CondWork<double> cw;
+        const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
+        const size_t n = (size_t)cond_layout(cw, s->cfg.N, N2) * Bp * e;
+        HIP_TRY(s, hipMalloc(&s->cond, n));
+        s->ws_bytes += n;
+    }
     return 0;
 }
 
@@ -228,7 +244,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->cond, s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -266,7 +282,14 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
     HIP_TRY(s, hipGetLastError());
     HIP_TRY(s, hipEventRecord(s->ev[1], st));
-    if (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) {
+    if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
+        CondWork<T> cw;
+        const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
+        cond_layout(cw, s->cfg.N, N2);
+        cw.base = (T *)s->cond;
+        cw.Bp = s->Bp;
+        hipLaunchKernelGGL(k_cond_ipm<T>, grid, block, 0, st, c, w, cw, out, B);
+    } else if (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) {
         TeamWork<T> tw;
         tw.tLM = (T *)s->LM;
         tw.tIV = (T *)s->iv;

@@ -9,6 +9,7 @@
 
 #include "../../include/rotors_nmpc.h"
 #include "../../rotors_mpc_controller_amd/csrc/nmpc_consts.hpp"
+#include "../../rotors_mpc_controller_amd/csrc/nmpc_cond.hpp"
 #include "../../rotors_mpc_controller_amd/csrc/nmpc_ipm.hpp"
 
 using namespace nmpc;
@@ -35,7 +36,16 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
     Inputs<T> in{hx0.data(), hy.data(), hye.data(), x_init ? hxi.data() : nullptr, x_init ? hui.data() : nullptr, bcast};
     Outputs<T> out{ou0.data(), oxo.data(), ouo.data()};
     for (int lane = 0; lane < B; lane++) lane_prepare(c, w, in, lane);
-    for (int lane = 0; lane < B; lane++) lane_ipm(c, w, out, lane);
+    if (g.flags & NMPC_FLAG_CONDENSED_QP) {
+        CondWork<T> cw;
+        const int N2 = (g.qp_cond_N > 0 && g.qp_cond_N < g.N) ? g.qp_cond_N : g.N;
+        std::vector<T> cbuf((size_t)cond_layout(cw, g.N, N2) * Bp);
+        cw.base = cbuf.data();
+        cw.Bp = (int)Bp;
+        for (int lane = 0; lane < B; lane++) lane_cond_ipm(c, w, cw, out, lane);
+    } else {
+        for (int lane = 0; lane < B; lane++) lane_ipm(c, w, out, lane);
+    }
     for (size_t i = 0; i < ou0.size(); i++) u0[i] = ou0[i];
     if (x_out) for (size_t i = 0; i < oxo.size(); i++) x_out[i] = oxo[i];
     if (u_out) for (size_t i = 0; i < ouo.size(); i++) u_out[i] = ouo[i];

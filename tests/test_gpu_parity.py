@@ -198,3 +198,21 @@ def test_argument_errors_raise():
         s.set(0, "x", np.zeros(5))
     with pytest.raises(NmpcError):
         s.set(3, "lbx", np.zeros(13))
+
+
+@pytest.mark.parametrize("N,cond_N", [(20, 5), (20, 3), (7, 5)])
+def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
+    """SURVEY 8a7 on the GPU: k_cond_ipm (condense -> IPM on dense blocks -> expand) vs the oracle's
+    condensed solve, and vs the team kernel on the uncondensed QP (solution invariance, U8)."""
+    sc = make_solver(N=N, qp_cond_N=cond_N, flags=_lib.FLAG_CONDENSED_QP | 1, max_batch=128)
+    st = make_solver(N=N, flags=_lib.FLAG_TEAM_MAPPING | 1, max_batch=128)
+    yref, ye = hover(sc.config)
+    x0 = sample_x0(100, 4, **AGGRESSIVE)
+    oc = sc.solve_batch(x0, yref, ye, want_traj=True)
+    ot = st.solve_batch(x0, yref, ye, want_traj=True)
+    ref = O.solve_batch(oracle_cfg(N=N, qp_cond_N=cond_N), x0, yref, ye, want_traj=True)
+    assert (oc["status"] == 0).all()
+    np.testing.assert_allclose(oc["u0"], ref["u0"], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(oc["x"], ref["x"], rtol=0, atol=TOL_X)
+    np.testing.assert_allclose(oc["u0"], ot["u0"], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(oc["u"], ot["u"], rtol=0, atol=TOL_X)

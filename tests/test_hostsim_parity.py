@@ -66,3 +66,19 @@ def test_fp32_kernel_arithmetic_is_close():
     out = H.solve_batch(cfg, x0, yref, ye)
     ref = O.solve_batch(O.default_config(qp_gamma=0.0), x0, yref, ye)
     assert (out["status"] == 0).all() and np.abs(out["u0"] - ref["u0"]).max() < 5e-3
+
+
+@pytest.mark.parametrize("N,cond_N,flags", [(20, 5, 4), (20, 5, 5), (20, 3, 4), (7, 5, 4), (20, 1, 4)])
+def test_partial_condensing_path_matches_oracle(N, cond_N, flags):
+    """condensing + IPM on the condensed QP (what acados hands to HPIPM, controller.py:181,184)
+    gives the oracle's condensed result and the uncondensed result (U8)."""
+    cfg = _lib.default_config(N=N, qp_cond_N=cond_N, flags=flags)
+    yref, ye = hover_reference(N, cfg.mass * cfg.gravity / 4.0)
+    x0 = sample_x0(10, 3, **AGGRESSIVE)
+    out = H.solve_batch(cfg, x0, yref, ye)
+    ref_c = O.solve_batch(O.default_config(qp_gamma=0.0, N=N, qp_cond_N=cond_N), x0, yref, ye, want_traj=True)
+    ref_u = O.solve_batch(O.default_config(qp_gamma=0.0, N=N), x0, yref, ye)
+    np.testing.assert_array_equal(out["iters"], ref_c["iters"])
+    np.testing.assert_allclose(out["u0"], ref_c["u0"], rtol=0, atol=1e-11)
+    np.testing.assert_allclose(out["x"], ref_c["x"], rtol=0, atol=1e-10)
+    np.testing.assert_allclose(out["u0"], ref_u["u0"], rtol=0, atol=1e-9)
