@@ -100,7 +100,10 @@ class PositionNMPC:
     """Nonlinear MPC for the rotor-level quadrotor model, solved on the GPU."""
 
     def __init__(self, params: Mapping[str, Mapping[str, object]], *, max_batch: int = 1, device: int = 0,
-                 dtype: int = _lib.DTYPE_F64, **solver_overrides) -> None:
+                 dtype: int = _lib.DTYPE_F64, solver_factory=None, **solver_overrides) -> None:
+        # solver_factory(NmpcConfig) -> object with set/solve/get/close; default: the HIP library.
+        # (Tests inject an oracle-backed stand-in to exercise this class without a GPU.)
+        self._solver_factory = solver_factory or NmpcOcpSolver
         self._solver: Optional[NmpcOcpSolver] = None
         self._opts = dict(max_batch=max_batch, device=device, dtype=dtype, **solver_overrides)
         self._prev_solution: Optional[Dict[str, np.ndarray]] = None
@@ -116,7 +119,7 @@ class PositionNMPC:
         self.nx, self.nu = 13, 4
         self.ny, self.ny_e = 17, 13
         self.nmpc_config = to_nmpc_config(self.config, **self._opts)
-        self._solver = NmpcOcpSolver(self.nmpc_config)
+        self._solver = self._solver_factory(self.nmpc_config)
         N = self.config.horizon_steps
         self._prev_solution = {"u": np.zeros((N, self.nu)), "x": np.zeros((N + 1, self.nx))}
         self._prev_solution_valid = False

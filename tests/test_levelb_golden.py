@@ -1,0 +1,58 @@
+"""Golden vectors produced by running the reference's UNMODIFIED controller.py on the Level-B shims
+(tests/golden/make_levelb_golden.py).  They pin this package's PositionNMPC façade -- quaternion
+normalisation, x0 pin, cold / unshifted warm start, yref stacking (controller.py:385-463) and the
+parameter derivation (:63-172) -- against the reference's own code."""
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from rotors_mpc_controller_amd.controller import PositionNMPC
+from rotors_mpc_controller_amd.params import load_params
+from rotors_mpc_controller_amd.reference import ReferenceGenerator
+
+GOLD = np.load(Path(__file__).parent / "golden" / "levelb_closed_loop.npz")
+
+
+def _replay(ctrl, tol):
+    params = load_params()
+    assert ctrl.horizon == int(GOLD["horizon"]) and ctrl.dt == float(GOLD["dt"])
+    assert abs(ctrl.hover_thrust - float(GOLD["hover_thrust"])) < 1e-15
+    np.testing.assert_array_equal(ctrl.input_bounds[0], GOLD["lbu"])
+    np.testing.assert_array_equal(ctrl.input_bounds[1], GOLD["ubu"])
+    for run in range(GOLD["states"].shape[0]):
+        gen = ReferenceGenerator(params["reference"])
+        gen.set_target(position=GOLD["setpoints"][run], yaw=float(GOLD["yaws"][run]))
+        gen.update_hover_thrust(ctrl.hover_thrust)
+        ctrl._prev_solution_valid = False
+        for t in range(GOLD["states"].shape[1]):
+            s = GOLD["states"][run, t]
+            state = dict(position=s[0:3], velocity=s[3:6], quaternion=s[6:10], body_rates=s[10:13])
+            u0, st = ctrl.solve(state, gen.build_horizon(ctrl.horizon, ctrl.dt))
+            assert st == int(GOLD["status"][run, t])
+            np.testing.assert_allclose(u0, GOLD["cmds"][run, t], rtol=0, atol=tol,
+                                       err_msg=f"run {run} tick {t}")
+
+
+def test_facade_on_oracle_backend_reproduces_reference_controller(monkeypatch):
+    monkeypatch.delenv("ROTORS_MPC_PARAMS", raising=False)
+    from tests.oracle_solver import OracleOcpSolver
+    ctrl = PositionNMPC(load_params(), solver_factory=OracleOcpSolver)
+    # same oracle underneath; the only difference is the inertia scale recovered by probing (ratios)
+    _replay(ctrl, tol=1e-11)
+
+
+@pytest.mark.gpu
+def test_facade_on_hip_backend_reproduces_reference_controller(monkeypatch):
+    monkeypatch.delenv("ROTORS_MPC_PARAMS", raising=False)
+    ctrl = PositionNMPC(load_params())
+    _replay(ctrl, tol=1e-9)
+
+
+def test_zero_quaternion_raises_like_the_reference():
+    from tests.oracle_solver import OracleOcpSolver
+    ctrl = PositionNMPC(load_params(), solver_factory=OracleOcpSolver)
+    gen = ReferenceGenerator({})
+    with pytest.raises(ValueError):
+        ctrl.solve(dict(position=[0, 0, 1], velocity=[0, 0, 0], quaternion=[0, 0, 0, 0], body_rates=[0, 0, 0]),
+                   gen.build_horizon(ctrl.horizon, ctrl.dt))
