@@ -143,7 +143,7 @@ void nmpc_default_config(nmpc_config *c)
     c->dtype = NMPC_DTYPE_F64;
     c->device = 0;
     c->max_batch = 4096;
-    c->flags = NMPC_FLAG_SHARE_COLD_START;
+    c->flags = NMPC_FLAG_SHARE_COLD_START | NMPC_FLAG_TEAM_MAPPING;
 }
 
 static int alloc_ws(nmpc_solver *s)
