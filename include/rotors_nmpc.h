@@ -81,6 +81,14 @@ typedef struct nmpc_config {
     int32_t device;            /* HIP device ordinal */
     int32_t max_batch;         /* workspace is sized for this many instances */
     uint32_t flags;            /* NMPC_FLAG_* */
+    /* Active-set polish of the QP (team mapping only; not in HPIPM): pin the bounds the iterate marks
+     * active, solve the remaining LQ problem exactly, accept only if the KKT conditions of the QP hold
+     * (then the result is the exact QP solution); otherwise correct the active set (primal-dual
+     * active-set step) or fall back to the interior point iteration.                                  */
+    int32_t qp_polish;         /* 0 = plain IPM, 1 = on */
+    int32_t qp_polish_passes;  /* active-set corrections per attempt */
+    int32_t qp_polish_budget;  /* no new attempt after this many passes */
+    double qp_polish_mu;       /* first attempt when mu <= this (>= mu0: before any IPM iteration), then every 100x below */
 } nmpc_config;
 
 typedef struct nmpc_stats {
@@ -91,6 +99,9 @@ typedef struct nmpc_stats {
     double ms_prepare;         /* device time of the linearisation kernel (HIP events) */
     double ms_solve;           /* device time of the IPM kernel */
     uint64_t workspace_bytes;
+    double polish_mean;        /* active-set passes per instance (team mapping), mean / max */
+    int32_t polish_max;
+    int32_t n_polished;        /* instances that finished with an accepted active-set solution */
 } nmpc_stats;
 
 typedef struct nmpc_solver nmpc_solver; /* opaque; owns all device memory */

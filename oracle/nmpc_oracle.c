@@ -62,6 +62,10 @@ void orc_default_config(orc_config *c)
     c->qp_thr0 = 0.1;
     c->qp_thr0_rel = 0.25;
     c->qp_gamma = 0.0;   /* optional safeguard; the HIP kernels do not implement it */
+    c->qp_polish = 0;
+    c->qp_polish_mu = 1.0;      /* >= mu0: the first attempt is a pure active-set solve from 'all free' */
+    c->qp_polish_passes = 5;
+    c->qp_polish_budget = 8;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -491,6 +495,140 @@ static void riccati_forward(const ocpqp *p, const ricc_fact *f, const double *dx
     }
 }
 
+/* Active-set polish of an interior-point iterate (not in HPIPM; an exactness/latency device of this
+ * build, mirrored by the team kernel).  Classify every bound pair from the current iterate (a bound
+ * is taken as active when its multiplier exceeds its slack), pin those inputs at their bounds, solve
+ * the remaining equality-constrained LQ problem exactly with one Riccati factorisation, and ACCEPT
+ * the result only if it satisfies the KKT conditions of the original QP: free inputs inside their
+ * box and multipliers of the pinned inputs of the right sign (costates by the adjoint recursion).
+ * An accepted point is THE solution of the strictly convex QP; a rejected one costs one sweep and the
+ * IPM simply continues.  Returns 1 if accepted (u, x overwritten; ll, lu set to the multipliers).    */
+static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, double **u, double **ll,
+                        double **lu, double *x, int max_pass, int *passes)
+{
+    const int N = p->N;
+    ocpqp m = *p;
+    m.B = (double **)malloc(sizeof(double *) * N); m.b = (double **)malloc(sizeof(double *) * N);
+    m.R = (double **)malloc(sizeof(double *) * N); m.S = (double **)malloc(sizeof(double *) * N);
+    m.q = (double **)malloc(sizeof(double *) * N); m.r = (double **)malloc(sizeof(double *) * N);
+    double **zero = (double **)malloc(sizeof(double *) * N), **uh = (double **)malloc(sizeof(double *) * N);
+    int **pin = (int **)malloc(sizeof(int *) * N), **newpin = (int **)malloc(sizeof(int *) * N);
+    double **gsave = (double **)malloc(sizeof(double *) * N);
+    double *xh = dalloc((size_t)(N + 1) * NX);
+    for (int k = 0; k < N; k++) {
+        const int nu = p->nu[k];
+        m.B[k] = dalloc((size_t)NX * nu); m.b[k] = dalloc(NX); m.R[k] = dalloc((size_t)nu * nu);
+        m.S[k] = dalloc((size_t)nu * NX); m.q[k] = dalloc(NX); m.r[k] = dalloc(nu);
+        zero[k] = dalloc(nu); uh[k] = dalloc(nu); pin[k] = (int *)calloc((size_t)nu, sizeof(int));
+        newpin[k] = (int *)calloc((size_t)nu, sizeof(int)); gsave[k] = dalloc(nu);
+        memcpy(m.B[k], p->B[k], sizeof(double) * NX * nu); memcpy(m.b[k], p->b[k], sizeof(double) * NX);
+        memcpy(m.R[k], p->R[k], sizeof(double) * nu * nu); memcpy(m.S[k], p->S[k], sizeof(double) * nu * NX);
+        memcpy(m.q[k], p->q[k], sizeof(double) * NX); memcpy(m.r[k], p->r[k], sizeof(double) * nu);
+        for (int i = 0; i < nu; i++) {
+            const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+            pin[k][i] = ll[k][i] > tl ? -1 : (lu[k][i] > tu ? 1 : 0);
+        }
+        for (int i = 0; i < nu; i++) {
+            if (!pin[k][i]) continue;
+            const double v = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
+            for (int l = 0; l < NX; l++) { m.b[k][l] += p->B[k][l * nu + i] * v; m.q[k][l] += p->S[k][i * NX + l] * v; }
+            for (int j = 0; j < nu; j++) if (!pin[k][j]) m.r[k][j] += p->R[k][j * nu + i] * v;
+        }
+        for (int i = 0; i < nu; i++) {
+            if (!pin[k][i]) continue;
+            const double v = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
+            for (int l = 0; l < NX; l++) { m.B[k][l * nu + i] = 0.0; m.S[k][i * NX + l] = 0.0; }
+            for (int j = 0; j < nu; j++) if (j != i) { m.R[k][i * nu + j] = 0.0; m.R[k][j * nu + i] = 0.0; }
+            m.r[k][i] = -m.R[k][i * nu + i] * v;
+        }
+    }
+    int ok = 0;
+    for (int pass = 0; pass < max_pass && !ok; pass++) {
+        if (pass > 0) {   /* rebuild the pinned problem for the corrected active set */
+            for (int k = 0; k < N; k++) {
+                const int nu = p->nu[k];
+                memcpy(m.B[k], p->B[k], sizeof(double) * NX * nu); memcpy(m.b[k], p->b[k], sizeof(double) * NX);
+                memcpy(m.R[k], p->R[k], sizeof(double) * nu * nu); memcpy(m.S[k], p->S[k], sizeof(double) * nu * NX);
+                memcpy(m.q[k], p->q[k], sizeof(double) * NX); memcpy(m.r[k], p->r[k], sizeof(double) * nu);
+                for (int i = 0; i < nu; i++) {
+                    if (!pin[k][i]) continue;
+                    const double v = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
+                    for (int l = 0; l < NX; l++) { m.b[k][l] += p->B[k][l * nu + i] * v; m.q[k][l] += p->S[k][i * NX + l] * v; }
+                    for (int j = 0; j < nu; j++) if (!pin[k][j]) m.r[k][j] += p->R[k][j * nu + i] * v;
+                }
+                for (int i = 0; i < nu; i++) {
+                    if (!pin[k][i]) continue;
+                    const double v = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
+                    for (int l = 0; l < NX; l++) { m.B[k][l * nu + i] = 0.0; m.S[k][i * NX + l] = 0.0; }
+                    for (int j = 0; j < nu; j++) if (j != i) { m.R[k][i * nu + j] = 0.0; m.R[k][j * nu + i] = 0.0; }
+                    m.r[k][i] = -m.R[k][i * nu + i] * v;
+                    zero[k][i] = 0.0;
+                }
+            }
+        }
+        (*passes)++;
+        if (riccati_backward(&m, zero, m.r, 0, 1, (ricc_fact *)f, NULL)) break;
+        riccati_forward(&m, f, dx0, 0, uh, xh);
+        double pi[NX], pin_[NX];
+        int changed = 0, nanf = 0;
+        for (int i = 0; i < NX; i++) {
+            double s2 = p->qN[i];
+            for (int j = 0; j < NX; j++) s2 += p->QN[i * NX + j] * xh[N * NX + j];
+            pi[i] = s2;
+        }
+        for (int k = N - 1; k >= 0; k--) {
+            const int nu = p->nu[k];
+            for (int i = 0; i < nu; i++)
+                if (pin[k][i]) uh[k][i] = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
+            for (int i = 0; i < nu; i++) {
+                const double lo = p->lo[k][i], hi = p->hi[k][i];
+                if (pin[k][i]) {   /* multiplier sign */
+                    double g = p->r[k][i];
+                    for (int j = 0; j < nu; j++) g += p->R[k][i * nu + j] * uh[k][j];
+                    for (int j = 0; j < NX; j++) g += p->S[k][i * NX + j] * xh[k * NX + j] + p->B[k][j * nu + i] * pi[j];
+                    const double tol = 1e-9 * (1.0 + fabs(g));
+                    gsave[k][i] = g;
+                    if ((pin[k][i] < 0 && g < -tol) || (pin[k][i] > 0 && g > tol)) { newpin[k][i] = 0; changed = 1; }
+                    else newpin[k][i] = pin[k][i];
+                } else {           /* primal feasibility */
+                    const double tol = 1e-9 * (1.0 + fabs(lo) + fabs(hi));
+                    if (!(uh[k][i] == uh[k][i])) nanf = 1;
+                    if (uh[k][i] < lo - tol) { newpin[k][i] = -1; changed = 1; }
+                    else if (uh[k][i] > hi + tol) { newpin[k][i] = 1; changed = 1; }
+                    else newpin[k][i] = 0;
+                }
+            }
+            for (int i = 0; i < NX; i++) {
+                double s2 = p->q[k][i];
+                for (int j = 0; j < NX; j++) s2 += p->Q[k][i * NX + j] * xh[k * NX + j] + p->A[k][j * NX + i] * pi[j];
+                for (int j = 0; j < nu; j++) s2 += p->S[k][j * NX + i] * uh[k][j];
+                pin_[i] = s2;
+            }
+            memcpy(pi, pin_, sizeof(pi));
+        }
+        for (int i = 0; i < (N + 1) * NX; i++) if (!(xh[i] == xh[i])) nanf = 1;
+        if (nanf) break;
+        if (!changed) { ok = 1; break; }
+        for (int k = 0; k < N; k++) memcpy(pin[k], newpin[k], sizeof(int) * (size_t)p->nu[k]);
+    }
+    if (ok) {
+        for (int k = 0; k < N; k++)
+            for (int i = 0; i < p->nu[k]; i++) {
+                u[k][i] = uh[k][i];
+                ll[k][i] = pin[k][i] < 0 ? fmax(gsave[k][i], 0.0) : 0.0;
+                lu[k][i] = pin[k][i] > 0 ? fmax(-gsave[k][i], 0.0) : 0.0;
+            }
+        memcpy(x, xh, sizeof(double) * (size_t)(N + 1) * NX);
+    }
+    for (int k = 0; k < N; k++) {
+        free(m.B[k]); free(m.b[k]); free(m.R[k]); free(m.S[k]); free(m.q[k]); free(m.r[k]);
+        free(zero[k]); free(uh[k]); free(pin[k]); free(newpin[k]); free(gsave[k]);
+    }
+    free(newpin); free(gsave);
+    free(m.B); free(m.b); free(m.R); free(m.S); free(m.q); free(m.r); free(zero); free(uh); free(pin); free(xh);
+    return ok;
+}
+
 /* [UPSTREAM] HPIPM-style Mehrotra predictor-corrector interior point method on the
  * OCP-QP, Riccati factorisation of the KKT system, cold-started every call (U9).
  * Feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
@@ -529,7 +667,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
             lu[k][i] = c->qp_mu0 / (hi - v);
         }
     }
-    double rho = 1.0, mu = 0.0;
+    double rho = 1.0, mu = 0.0, pol_mu = c->qp_polish_mu;
+    int polished = 0, npolish = 0;
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
     for (;;) {
         mu = 0.0;
@@ -539,6 +678,10 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         mu /= nc;
         if (!(mu == mu)) { status = 1; break; }
         if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat) break;
+        if (c->qp_polish && mu <= pol_mu && npolish < c->qp_polish_budget) {
+            if (ocpqp_polish(p, dx0, &f, u, ll, lu, x, c->qp_polish_passes, &npolish)) { polished = 1; mu = 0.0; rho = 0.0; break; }
+            pol_mu *= 1e-2;
+        }
         if (it >= itmax) { status = 2; break; }
         it++;
         /* predictor (affine scaling) */
@@ -633,7 +776,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     }
     /* final rollout of the states from the inputs (dynamics are affine) */
     for (int i = 0; i < NX; i++) x[i] = dx0 ? dx0[i] : 0.0;
-    for (int k = 0; k < N; k++)
+    if (!polished) for (int k = 0; k < N; k++)
         for (int i = 0; i < NX; i++) {
             double s = p->b[k][i];
             for (int j = 0; j < NX; j++) s += p->A[k][i * NX + j] * x[k * NX + j];
@@ -671,7 +814,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
             memcpy(pi, pin, sizeof(pi));
         }
         st->qp_iter = it; st->qp_status = status; st->res_stat = rs; st->res_eq = 0.0;
-        st->res_comp = rc; st->mu = mu; st->rho = rho;
+        st->res_comp = rc; st->mu = mu; st->rho = rho; st->polished = polished; st->polish_attempts = npolish;
     }
     for (int k = 0; k < N; k++) {
         free(f.L[k]); free(f.M[k]); free(f.m[k]); free(ll[k]); free(lu[k]); free(sig[k]);

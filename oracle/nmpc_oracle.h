@@ -55,6 +55,10 @@ typedef struct orc_config {
     double qp_thr0;         /* initial distance from the bounds (absolute) */
     double qp_thr0_rel;     /* ... and relative to the box width; the larger applies */
     double qp_gamma;        /* centrality safeguard: products >= gamma*mu after a step; 0 = off */
+    int qp_polish;          /* 1: active-set polish once mu <= qp_polish_mu (then every 100x below) */
+    double qp_polish_mu;
+    int qp_polish_passes;   /* primal-dual active-set corrections per polish attempt */
+    int qp_polish_budget;   /* no further attempt once this many passes were spent */
 } orc_config;
 
 typedef struct orc_stats {
@@ -66,6 +70,8 @@ typedef struct orc_stats {
     double mu;              /* barrier parameter at exit */
     double rho;             /* tracked relative stationarity factor prod(1-alpha) */
     int hess_projected;     /* PROJECT_REDUC_HESS had to act (expected 0) */
+    int polished;           /* the active-set polish was accepted */
+    int polish_attempts;
 } orc_stats;
 
 /* defaults = reference config/params.yaml + acados option defaults */

@@ -29,6 +29,7 @@ class OrcConfig(C.Structure):
         ("qp_tol_comp", C.c_double), ("qp_tol_stat", C.c_double),
         ("qp_mu0", C.c_double), ("qp_tau", C.c_double), ("qp_thr0", C.c_double),
         ("qp_thr0_rel", C.c_double), ("qp_gamma", C.c_double),
+        ("qp_polish", C.c_int), ("qp_polish_mu", C.c_double), ("qp_polish_passes", C.c_int), ("qp_polish_budget", C.c_int),
     ]
 
 
@@ -37,6 +38,7 @@ class OrcStats(C.Structure):
         ("qp_iter", C.c_int), ("qp_status", C.c_int),
         ("res_stat", C.c_double), ("res_eq", C.c_double), ("res_comp", C.c_double),
         ("mu", C.c_double), ("rho", C.c_double), ("hess_projected", C.c_int),
+        ("polished", C.c_int), ("polish_attempts", C.c_int),
     ]
 
 

@@ -39,6 +39,8 @@ class NmpcConfig(C.Structure):
         ("qp_tol_comp", C.c_double), ("qp_tol_stat", C.c_double), ("qp_mu0", C.c_double),
         ("qp_tau", C.c_double), ("qp_thr0", C.c_double), ("qp_thr0_rel", C.c_double),
         ("dtype", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_uint32),
+        ("qp_polish", C.c_int32), ("qp_polish_passes", C.c_int32), ("qp_polish_budget", C.c_int32),
+        ("qp_polish_mu", C.c_double),
     ]
 
     def update(self, **over) -> "NmpcConfig":
@@ -60,6 +62,7 @@ class NmpcStats(C.Structure):
         ("batch", C.c_int32), ("iter_min", C.c_int32), ("iter_max", C.c_int32),
         ("iter_mean", C.c_double), ("n_status", C.c_int32 * 5),
         ("ms_prepare", C.c_double), ("ms_solve", C.c_double), ("workspace_bytes", C.c_uint64),
+        ("polish_mean", C.c_double), ("polish_max", C.c_int32), ("n_polished", C.c_int32),
     ]
 
 

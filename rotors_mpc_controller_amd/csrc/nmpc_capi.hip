@@ -67,7 +67,7 @@ struct nmpc_solver {
     size_t esz = 8;
     // device workspace (element type = cfg.dtype)
     void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *cond = nullptr;
-    int32_t *d_iters = nullptr, *d_status = nullptr;
+    int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
     void *s_x0 = nullptr, *s_yref = nullptr, *s_yref_e = nullptr, *s_xi = nullptr, *s_ui = nullptr;
@@ -144,6 +144,10 @@ void nmpc_default_config(nmpc_config *c)
     c->device = 0;
     c->max_batch = 4096;
     c->flags = NMPC_FLAG_SHARE_COLD_START | NMPC_FLAG_TEAM_MAPPING;
+    c->qp_polish = 1;
+    c->qp_polish_passes = 5;
+    c->qp_polish_budget = 8;
+    c->qp_polish_mu = 1.0;
 }
 
 static int alloc_ws(nmpc_solver *s)
@@ -154,7 +158,7 @@ static int alloc_ws(nmpc_solver *s)
         {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bp * e},
         {&s->iv, N * IV_ROWS * Bp * e},
         {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bp : 1) * e}, {(void **)&s->d_iters, Bp * sizeof(int32_t)},
-        {(void **)&s->d_status, Bp * sizeof(int32_t)}};
+        {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)}};
     for (auto &x : a) {
         HIP_TRY(s, hipMalloc(x.p, x.n));
         s->ws_bytes += x.n;
@@ -244,7 +248,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->cond, s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->d_npol, s->cond, s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -270,6 +274,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     w.AB = (T *)s->AB; w.bv = (T *)s->bv; w.qr = (T *)s->qr; w.xl = (T *)s->xl; w.ul = (T *)s->ul;
     w.LM = (T *)s->LM; w.iv = (T *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
     w.prof = s->d_prof;
+    w.npol = s->d_npol;
     w.tAB = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? (T *)s->tAB : nullptr;
     Inputs<T> in;
     in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
@@ -279,6 +284,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out;
     const dim3 grid((B + 63) / 64), block(64);
     HIP_TRY(s, hipEventRecord(s->ev[0], st));
+    HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));
     hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
     HIP_TRY(s, hipGetLastError());
     HIP_TRY(s, hipEventRecord(s->ev[1], st));
@@ -602,6 +608,16 @@ int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out)
         if (st[i] >= 0 && st[i] < 5) out->n_status[st[i]]++;
     }
     out->iter_mean = sum / B;
+    std::vector<int32_t> np(B);
+    HIP_TRY(s, hipMemcpy(np.data(), s->d_npol, (size_t)B * 4, hipMemcpyDeviceToHost));
+    double psum = 0;
+    for (int i = 0; i < B; i++) {
+        const int a = std::abs(np[i]);
+        psum += a;
+        out->polish_max = std::max(out->polish_max, a);
+        out->n_polished += (np[i] > 0);
+    }
+    out->polish_mean = psum / B;
     return 0;
 }
 

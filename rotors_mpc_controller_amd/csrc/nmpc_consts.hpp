@@ -48,6 +48,10 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.tau = (T)g.qp_tau;
     c.thr0 = (T)g.qp_thr0;
     c.thr0_rel = (T)g.qp_thr0_rel;
+    c.polish = g.qp_polish;
+    c.polish_passes = g.qp_polish_passes;
+    c.polish_budget = g.qp_polish_budget;
+    c.polish_mu = (T)g.qp_polish_mu;
 }
 
 

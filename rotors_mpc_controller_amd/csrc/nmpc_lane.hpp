@@ -59,6 +59,9 @@ struct Consts {
     T fuw[3][NU];                     // d omegadot / d u  (rotor geometry / inertia)
     T rx[NU], ry[NU], rz[NU];
     T tol_comp, tol_stat, mu0, tau, thr0, thr0_rel;
+    // active-set polish (team kernel only; the lane and condensed kernels are plain IPM)
+    int polish, polish_passes, polish_budget;
+    T polish_mu;
 };
 
 // SoA workspace: row r of an array is the contiguous run [r*Bp, r*Bp + Bp)
@@ -74,6 +77,7 @@ struct Work {
     T *iv;    // [N][20][Bp]
     int32_t *iters;   // [Bp]
     int32_t *status;  // [Bp]
+    int32_t *npol;    // [Bp] active-set passes spent (team kernel), or null
     T *tAB;           // [B][Ns][176] per-instance copy of (Ad rows | B rows | b) for the team kernel, or null
     long long *prof;  // [8][Bp] per-sweep time stamps, NMPC_PROFILE builds only (else null)
 };

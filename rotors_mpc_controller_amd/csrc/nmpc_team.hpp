@@ -15,8 +15,9 @@
 // Cholesky pivots use v_rsq_f64 + 2 Newton steps.
 //
 // Per-instance scratch in HBM is "array of structures" (a team reads contiguous runs):
-//   tLM [inst][stage][72] : M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | pad
-//   tIV [inst][stage][20] : u | lam_l | lam_u | u_aff | du   (4 each)
+//   tLM [inst][stage][80] : M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | xhat (13) | pad
+//   tIV [inst][stage][20] : u | lam_l | lam_u | u_aff | du   (4 each); during an active-set pass the last
+//                           two hold the candidate inputs and the pin codes (-1 lower, 0 free, +1 upper)
 // Inputs of the stage matrices come from the SoA workspace written by k_prepare.
 #pragma once
 
@@ -26,7 +27,7 @@ namespace nmpc {
 
 constexpr int TEAM = 16;            // lanes per instance (one DPP row)
 constexpr int TEAMS_PER_WAVE = 4;
-constexpr int TLM_ROWS = 72;
+constexpr int TLM_ROWS = 80;       // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad
 constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
 // LDS carve per team, in elements of T
 constexpr int L_AD = 0;             // [16][8]   rows of the dense A columns
@@ -37,13 +38,13 @@ constexpr int L_H = L_PB + 64;      // [16]
 constexpr int L_PA = L_H + 16;      // [16][14]  rows of P*A
 constexpr int L_HG = L_PA + 224;    // [16]      Huu (10) | gu (4)
 constexpr int L_MC = L_HG + 16;     // [16][4]   columns of M
-constexpr int L_D = L_MC + 64;      // [4] D | [4] rhat
-constexpr int L_Y = L_D + 8;        // [2][16][4] partial products M[:,c]*x_c, double buffered
+constexpr int L_D = L_MC + 64;      // [4] D | [4] rhat | [4] free mask | [4] pinned value
+constexpr int L_Y = L_D + 16;       // [2][16][4] partial products M[:,c]*x_c, double buffered
 constexpr int L_XH = L_Y + 128;     // [2][16]
 constexpr int L_DR = L_XH + 32;     // [2][4]
 constexpr int L_RED = L_DR + 8;     // [32] small reductions
 constexpr int L_Z = L_RED + 32;     // [32] the 28 entries of the (q,omega)x(q,omega) block of A'PA
-// 840 elements: as bytes (6720 B FP64 / 3360 B FP32) the team stride is 64 B resp. 32 B past a
+// 848 elements: as bytes (6784 B FP64 / 3392 B FP32) the team stride is 128 B resp. 64 B past a
 // multiple of the 256-B LDS bank row, so the four teams of a wave - which issue the same relative
 // address at the same time - fall on different banks.  (A stride of 800 doubles = 25 bank rows
 // made every broadcast read a 4-way conflict: SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles.)
@@ -196,27 +197,33 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             ivk[j] = v;
             ivk[4 + j] = c.mu0 / (v - lo);
             ivk[8 + j] = c.mu0 / (hi - v);
+            ivk[16 + j] = 0;   // active-set guess: everything free
         }
     }
     __syncthreads();
     NMPC_PROF_BEGIN
-    T mu = c.mu0, rho = T(1);
-    int it = 0, status = 0;
-    bool done = false;
+    T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu;
+    int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
+    // per-team mode: interior point iteration, active-set (polish) pass, or finished
+    enum { M_IPM = 0, M_POL = 1, M_DONE = 2 };
+    int mode = M_IPM;
+    bool from_ua = false;   // the accepted active-set solution lives in the u_aff slot
     const T Qdr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Qd[i] : v; return v; }();
     const T QdNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.QdN[i] : v; return v; }();
 
     for (;;) {
-        // per-team termination test; the wave keeps sweeping until all its teams are done
-        if (!done) {
-            if (!(mu == mu)) { status = 1; done = true; }
-            else if (mu <= c.tol_comp && rho <= c.tol_stat) done = true;
-            else if (it >= c.iter_max) { status = 2; done = true; }
+        // per-team transitions; the wave keeps sweeping until all its teams are done
+        if (mode == M_IPM) {
+            if (!(mu == mu)) { status = 1; mode = M_DONE; }
+            else if (mu <= c.tol_comp && rho <= c.tol_stat) mode = M_DONE;
+            else if (c.polish && mu <= pol_mu && npol < c.polish_budget) { mode = M_POL; pass_in_attempt = 0; }
+            else if (it >= c.iter_max) { status = 2; mode = M_DONE; }
         }
-        if (__ballot(!done) == 0) break;
-        const bool act = !done;           // frozen teams keep computing but never store
+        if (__ballot(mode != M_DONE) == 0) break;
+        const bool pol = mode == M_POL, ipm = mode == M_IPM;
+        const bool act = mode != M_DONE;  // frozen teams keep computing but never store
         const bool st_ok = act && valid;
-        if (act) it++;
+        if (ipm) it++;
 
         // ================= sweep A: backward factorisation, affine right-hand side
         T Prow[NX], pv;
@@ -226,20 +233,30 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
         T n_ul = NMPC_LD(w.ul, (N - 1) * NU + j), n_u = tIV[(N - 1) * IV_ROWS + j],
           n_ll = tIV[(N - 1) * IV_ROWS + 4 + j], n_lu = tIV[(N - 1) * IV_ROWS + 8 + j],
+          n_pc = tIV[(N - 1) * IV_ROWS + 16 + j],
           n_rk = NMPC_LD(w.qr, (N - 1) * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, (N - 1) * QR_ROWS + rr);
         for (int k = N - 1; k >= 0; k--) {
             if (!SHARED) load_stage(k);
             T *lmk = tLM + k * TLM_ROWS;
-            const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr;
+            const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
             if (k > 0) {
                 const T *ivn = tIV + (k - 1) * IV_ROWS;
-                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j];
+                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; n_pc = ivn[16 + j];
                 n_rk = NMPC_LD(w.qr, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_LD(w.qr, (k - 1) * QR_ROWS + rr);
             }
-            {
-                const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
-                const T sg = pr.kl + pr.ku;
-                if (cmpl) { sD[j] = Rdj + sg; sD[4 + j] = rk - sg * u; }
+            {   // IPM: barrier terms.  Active-set pass: no barrier, pinned inputs are taken out of B
+                // (free mask) and enter through b (pinned value); their own row keeps R_jj so u_j = bound.
+                const T lo = lbj - ul, hi = ubj - ul;
+                const Pair<T> pr(u, ll, lu, lo, hi);
+                const T sg = pol ? T(0) : pr.kl + pr.ku;
+                const bool pinned = pol && pc != T(0);
+                const T vpin = pc < T(0) ? lo : hi;
+                if (cmpl) {
+                    sD[j] = Rdj + sg;
+                    sD[4 + j] = pinned ? -Rdj * vpin : (pol ? rk : rk - sg * u);
+                    sD[8 + j] = pinned ? T(0) : T(1);
+                    sD[12 + j] = pinned ? vpin : T(0);
+                }
             }
             // P1: row r of P*B, P*b + p, P*A.  The LDS operands are read in three batches with the
             // scheduler fenced in between: left alone, hipcc interleaves "one ds_read, wait, two
@@ -285,6 +302,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
             }
             NMPC_UNROLL for (int i = 0; i < 3; i++) { PArow[i] = Prow[i]; PArow[3 + i] = c.dt * Prow[i] + Prow[3 + i]; }
+            NMPC_UNROLL for (int i = 0; i < NU; i++) { h += PBrow[i] * sD[12 + i]; PBrow[i] *= sD[8 + i]; }
             NMPC_UNROLL for (int i = 0; i < NU; i++) sPB[r * 4 + i] = PBrow[i];
             sh[r] = h;
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) sPA[r * 14 + cc] = PArow[cc];
@@ -306,10 +324,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         a1[l] = sAd[l * 8 + za1]; t1[l] = sPA[l * 14 + 6 + zb1];
                     }
                 }
-                T a = e < 10 ? (ei == ej ? sD[ei] : T(0)) : sD[4 + ei];
+                const T a_c = e < 10 ? (ei == ej ? sD[ei] : T(0)) : sD[4 + ei], mk = sD[8 + ei];
                 if (BATCH) NMPC_SCHED_FENCE();
+                T a = 0;
                 NMPC_UNROLL for (int l = 0; l < NX; l++) a += xa[l] * xb[l];
-                sHg[r] = a;
+                sHg[r] = a_c + mk * a;
                 if (k > 0) {
                     T d0 = 0, d1 = 0;
                     NMPC_UNROLL for (int l = 0; l < NX; l++) { d0 += a0[l] * t0[l]; d1 += a1[l] * t1[l]; }
@@ -384,8 +403,14 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         }
         NMPC_STAMP(0)
         __syncthreads();   // L, m of every stage (written by lane 0) visible to the team
-        if (act && !ok) { status = nanp ? 1 : 4; done = true; }
-        const bool act2 = act && !done, st_ok2 = act2 && valid;
+        bool pol_fail = false;
+        if (act && !ok) {
+            if (nanp) { status = 1; mode = M_DONE; }
+            else if (pol) pol_fail = true;              // active-set pass: give up this attempt
+            else { status = 4; mode = M_DONE; }
+        }
+        const bool act2 = mode != M_DONE, st_ok2 = act2 && valid;
+        const bool ipm2 = act2 && ipm, pol2 = act2 && pol;
 
         // ================= sweep B: forward affine solve
         T xh = 0, rmax = T(1), s2 = 0;   // rmax: largest inverse step length, floor 1 => alpha_aff <= 1
@@ -425,7 +450,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 rmax = fmax(rmax, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
                 s2 += dla * d - dua * d;
             }
-            if (k < N - 1) {
+            if (pol2 && rowl && valid) tLM[k * TLM_ROWS + 66 + rr] = xh;   // xhat_k for the costate sweep
+            {   // also through the last stage: the active-set check needs xhat_N
                 T a = b_r;
                 a += (rr < 3) ? xh + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? xh : T(0));
                 NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
@@ -447,6 +473,62 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             sg3 = sg3 * sg3 * sg3;
             sigmu = sg3 * mu;
         }
+
+        // ================= sweep C (teams in an active-set pass): costates by the adjoint recursion,
+        // KKT check of the pinned solve, corrected active set (primal-dual active-set step)
+        if (__ballot(pol2) != 0) {
+            T pi_r = QdNr * xh + NMPC_LD(w.qr, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
+            T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
+            p = 0;
+            for (int k = N - 1; k >= 0; k--) {
+                if (!SHARED) load_stage(k);
+                T *ivk = tIV + k * IV_ROWS;
+                const T ul = NMPC_LD(w.ul, k * NU + j), uj = ivk[12 + j], pc = ivk[16 + j];
+                const T rk = NMPC_LD(w.qr, k * QR_ROWS + NX + j), q_r = NMPC_LD(w.qr, k * QR_ROWS + rr);
+                const T xk = k > 0 ? tLM[k * TLM_ROWS + 66 + rr] : T(0);
+                sXh[p * 16 + r] = pi_r;
+                NMPC_WSYNC();
+                const T lo = lbj - ul, hi = ubj - ul;
+                const T vpin = pc < T(0) ? lo : hi;
+                const T ue = pc != T(0) ? vpin : uj;            // pinned inputs sit exactly on the bound
+                T g = Rdj * ue + rk, an = 0;
+                NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                    const T pl = sXh[p * 16 + l];
+                    g += sB[l * 4 + j] * pl;
+                    an += Acol[l] * pl;
+                }
+                T npc;
+                if (pc != T(0)) {                                // multiplier sign of a pinned input
+                    const T tol = T(1e-9) * (T(1) + fabs(g));
+                    const bool wrong = (pc < T(0) && g < -tol) || (pc > T(0) && g > tol);
+                    npc = wrong ? T(0) : pc;
+                } else {                                         // free input inside its box?
+                    const T tol = T(1e-9) * (T(1) + fabs(lo) + fabs(hi));
+                    npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
+                }
+                chg += (npc != pc) ? T(1) : T(0);
+                nanf += (ue == ue && g == g && an == an) ? T(0) : T(1);
+                if (cmpl && pol2 && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
+                pi_r = Qdr * xk + q_r + an;
+                p ^= 1;
+            }
+            if (cmpl) { sRed[20 + j] = chg; sRed[24 + j] = nanf; }
+            __syncthreads();
+            chg = sRed[20] + sRed[21] + sRed[22] + sRed[23];
+            nanf = sRed[24] + sRed[25] + sRed[26] + sRed[27];
+            T xn = 0;                                            // NaN in any xhat row poisons the pass
+            sXh[r] = nanf;
+            __syncthreads();
+            NMPC_UNROLL for (int l = 0; l < NX; l++) xn += sXh[l];
+            if (pol2) {
+                npol++;
+                pass_in_attempt++;
+                if (!pol_fail && xn == T(0) && chg == T(0)) { mode = M_DONE; from_ua = true; mu = 0; rho = 0; }
+                else if (pol_fail || !(xn == T(0)) || pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
+            }
+            __syncthreads();
+        }
+        if (__ballot(ipm2) == 0) continue;   // nobody in this wave is iterating the interior point method
 
         // ================= sweep D: backward homogeneous solve
         pv = 0;
@@ -483,7 +565,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 mv[i] = a;
             }
             l_solve(Lf, mv);
-            if (r == 0 && st_ok2) {
+            if (r == 0 && ipm2 && valid) {
                 NMPC_UNROLL for (int i = 0; i < NU; i++) lmk[62 + i] = mv[i];
             }
             if (k > 0) {
@@ -528,7 +610,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
                 const T cl = dla * da, cu = -dua * da;
                 const T d = da + sel4(uh, j);
-                if (cmpl && st_ok2) ivk[16 + j] = d;
+                if (cmpl && ipm2 && valid) ivk[16 + j] = d;
                 const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
                 const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
                 rmax = fmax(rmax, fmax(-d * pr.itl, d * pr.itu));
@@ -562,16 +644,20 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
             const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
             u += alpha * d; ll += alpha * dl; lu += alpha * du;
-            if (cmpl && st_ok2) { ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu; }
+            if (cmpl && ipm2 && valid) {
+                ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu;
+                // active-set guess for a later polish attempt: a bound whose multiplier exceeds its slack
+                ivk[16 + j] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
+            }
             ms += ll * (u - lo) + lu * (hi - u);
         }
         NMPC_STAMP(4)
         if (cmpl) sRed[16 + j] = ms;
         __syncthreads();
         ms = sRed[16] + sRed[17] + sRed[18] + sRed[19];
-        if (act2) {
-            if (!(alpha == alpha)) { status = 1; done = true; }
-            else if (alpha < T(1e-12)) { status = 3; done = true; }
+        if (ipm2) {
+            if (!(alpha == alpha)) { status = 1; mode = M_DONE; }
+            else if (alpha < T(1e-12)) { status = 3; mode = M_DONE; }
             else {
                 rho *= (T(1) - alpha);
                 mu = ms / nc;
@@ -589,7 +675,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         const bool upd = (status == 0 || status == 2);
         for (int k = 0; k < N; k++) {
             if (!SHARED) load_stage(k);
-            const T u = tIV[k * IV_ROWS + j];
+            const T u = tIV[k * IV_ROWS + (from_ua ? 12 : 0) + j];
             if (cmpl) sDr[p * 4 + j] = u;
             sXh[p * 16 + r] = dx;
             NMPC_WSYNC();
@@ -617,7 +703,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     NMPC_PROF_END(w)
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     if (valid) {
-        if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; }
+        if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; if (w.npol) w.npol[inst] = from_ua ? npol : -npol; }   // > 0: accepted active-set solution
         if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? NMPC_LD(w.ul, j) : T(0);   // controller.py:448-452
         if (out.x_out && rowl) {
             for (int k = 0; k <= N; k++) out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = NMPC_LD(w.xl, k * NX + rr);

@@ -153,7 +153,8 @@ class NmpcOcpSolver:
         self._check(self._lib.nmpc_get_stats(self._h, C.byref(st)))
         return dict(batch=st.batch, iter_min=st.iter_min, iter_max=st.iter_max, iter_mean=st.iter_mean,
                     n_status=list(st.n_status), ms_prepare=st.ms_prepare, ms_solve=st.ms_solve,
-                    workspace_bytes=int(st.workspace_bytes))
+                    workspace_bytes=int(st.workspace_bytes), polish_mean=st.polish_mean, polish_max=st.polish_max,
+                    n_polished=st.n_polished)
 
 
 # name a maintainer would import in place of acados_template's class

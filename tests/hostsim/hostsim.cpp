@@ -32,7 +32,7 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
         ul(N * NU * Bp), LM(N * LM_ROWS * Bp), iv(N * IV_ROWS * Bp);
     std::vector<int32_t> it(Bp), st(Bp);
     std::vector<T> ou0((size_t)B * NU), oxo((size_t)B * (N + 1) * NX), ouo((size_t)B * N * NU);
-    Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), it.data(), st.data(), nullptr, nullptr};
+    Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), it.data(), st.data(), nullptr, nullptr, nullptr};
     Inputs<T> in{hx0.data(), hy.data(), hye.data(), x_init ? hxi.data() : nullptr, x_init ? hui.data() : nullptr, bcast};
     Outputs<T> out{ou0.data(), oxo.data(), ouo.data()};
     for (int lane = 0; lane < B; lane++) lane_prepare(c, w, in, lane);
