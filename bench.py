@@ -48,7 +48,7 @@ def cpu_baseline(B_sample: int, N: int):
     """The CPU oracle (a port, not acados) on this box's host cores, bounded sample."""
     from oracle import oracle as O
     from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, sample_x0
-    c = O.default_config(N=N, qp_gamma=0.0)
+    c = O.default_config(N=N, qp_gamma=0.0, qp_polish=1)      # same algorithm as the GPU default
     yref, ye = O.hover_yref(c)
     x0 = sample_x0(B_sample, 0, **NEAR_HOVER)
     cores = len(os.sched_getaffinity(0))
@@ -203,6 +203,7 @@ def main() -> None:
                                 batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
                                 traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather u0"),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
+                    active_set_passes=dict(mean=st["polish_mean"], max=st["polish_max"], accepted=st["n_polished"]),
                     status_histogram=st["n_status"], roofline=roof)
         if world == 1 and not args.no_cpu_baseline and args.dtype == "f64" and args.dist == "near_hover":
             ns = min(args.cpu_sample, B)

@@ -714,6 +714,112 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// Preparation phase in the team mapping (staging of controller.py:414-445 + linearisation, U2/U3):
+// lane r stages row r of every stage (coalesced 13- and 17-element runs of x0 / x_init / yref), and
+// lane c < 11 integrates column c of the forward sensitivities (4 quaternion, 3 body-rate, 4 input
+// columns) with the explicit-midpoint steps; the state itself and the four Jacobians are replicated
+// (cheap).  Writes the SoA rows the QP kernel reads (xl, ul, qr) and the per-instance stage block tAB.
+template <class T>
+__device__ __forceinline__ void vde_col_rt(const Consts<T> &c, const Jac<T> &J, const T *s, T *k, bool is_u, int ju)
+{
+    NMPC_UNROLL for (int i = 0; i < 3; i++) k[i] = s[3 + i];
+    NMPC_UNROLL for (int i = 0; i < 3; i++) {
+        T a = is_u ? J.r3m[i] : T(0);
+        NMPC_UNROLL for (int l = 0; l < 4; l++) a += J.Fvq[i][l] * s[6 + l];
+        k[3 + i] = a;
+    }
+    NMPC_UNROLL for (int i = 0; i < 4; i++) {
+        T a = 0;
+        NMPC_UNROLL for (int l = 0; l < 4; l++) a += J.Fqq[i][l] * s[6 + l];
+        NMPC_UNROLL for (int l = 0; l < 3; l++) a += J.Fqw[i][l] * s[10 + l];
+        k[6 + i] = a;
+    }
+    NMPC_UNROLL for (int i = 0; i < 3; i++) {
+        T a = is_u ? sel4(c.fuw[i], ju) : T(0);
+        NMPC_UNROLL for (int l = 0; l < 3; l++) a += J.Fww[i][l] * s[10 + l];
+        k[10 + i] = a;
+    }
+}
+
+template <class T>
+__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B)
+{
+    const int tid = threadIdx.x, team = tid >> 4, r = tid & 15;
+    const int rr = r < NX ? r : NX - 1, j = r & 3;
+    const bool rowl = r < NX, cmpl = r < NU;
+    int inst = blockIdx.x * (blockDim.x >> 4) + team;
+    const bool valid = inst < B;
+    if (!valid) inst = B - 1;
+    const int N = c.N, Bp = w.Bp, lane = inst;
+    const bool warm = in.x_init != nullptr && in.u_init != nullptr;
+    const T *x0 = in.x0 + (size_t)inst * NX;
+    const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
+    const T *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
+    const T *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : nullptr;
+    const T *ui = warm ? in.u_init + (size_t)inst * N * NU : nullptr;
+    const T Wqr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Wq[i] : v; return v; }();
+    const T WqNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.WqN[i] : v; return v; }();
+    const T Wrj = sel4(c.Wr, j);
+    // staging and cost gradients (U4)
+    for (int k = 0; k <= N; k++) {
+        const T xk = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0[rr];   // stage 0 is pinned to x0
+        if (rowl && valid) NMPC_ST(w.xl, k * NX + rr, xk);
+        if (k < N) {
+            const T uk = warm ? ui[(size_t)k * NU + j] : T(0);
+            if (valid) {
+                if (rowl) NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xk - yr[(size_t)k * NY + rr]));
+                if (cmpl) {
+                    NMPC_ST(w.ul, k * NU + j, uk);
+                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uk - yr[(size_t)k * NY + NX + j]));
+                }
+            }
+        } else if (rowl && valid) {
+            NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xk - ye[rr]));
+        }
+    }
+    // linearisation: one interval if the cold start lets all stages share it
+    const int Ns = c.shared ? 1 : N;
+    const int col = r < 11 ? r : 10;
+    const bool is_u = col >= 7;
+    for (int k = 0; k < Ns; k++) {
+        T xs[NX], us[NU], S[NX];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (warm && k > 0) ? xi[(size_t)k * NX + i] : x0[i];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = warm ? ui[(size_t)k * NU + i] : T(0);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) S[i] = (col < 7 && i == 6 + col) ? T(1) : T(0);
+        for (int st = 0; st < c.steps; st++) {
+            Jac<T> J1, J2;
+            T f1[NX], xm[NX], f2[NX], k1[NX], sm[NX], k2[NX];
+            model_f(c, xs, us, f1);
+            model_jac(c, xs, us, J1);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + T(0.5) * c.h * f1[i];
+            model_f(c, xm, us, f2);
+            model_jac(c, xm, us, J2);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += c.h * f2[i];
+            vde_col_rt(c, J1, S, k1, is_u, col - 7);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) sm[i] = S[i] + T(0.5) * c.h * k1[i];
+            vde_col_rt(c, J2, sm, k2, is_u, col - 7);
+            NMPC_UNROLL for (int i = 0; i < NX; i++) S[i] += c.h * k2[i];
+        }
+        if (valid) {
+            T *a = w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+            if (r < 7) {
+                NMPC_UNROLL for (int i = 0; i < NX; i++) a[i * 8 + r] = S[i];
+            } else if (r < 11) {
+                NMPC_UNROLL for (int i = 0; i < NX; i++) a[104 + i * NU + (r - 7)] = S[i];
+            }
+            if (rowl) {
+                a[rr * 8 + 7] = 0;
+                const T xn1 = (warm) ? xi[(size_t)(k + 1) * NX + rr] : x0[rr];
+                T xnr = 0;
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xnr = (i == rr) ? xs[i] : xnr;
+                a[156 + rr] = xnr - xn1;
+            }
+        }
+    }
+}
+
 #endif  // device
 
 }  // namespace nmpc

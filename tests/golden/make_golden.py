@@ -31,8 +31,11 @@ def golden_rti():
                          sample_x0(16, 2, sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)])
     yref, ye = hover_reference(c.N, c.mass * c.gravity / 4.0)
     out = O.solve_batch(c, x0, yref, ye, want_traj=True)
+    # the same instances with the active-set polish (exact QP solutions; the team kernel's default)
+    outp = O.solve_batch(O.default_config(qp_gamma=0.0, qp_polish=1), x0, yref, ye, want_traj=True)
     np.savez_compressed(HERE / "rti_cold_start.npz", x0=x0, yref=yref, yref_e=ye, u0=out["u0"],
-                        status=out["status"], iters=out["iters"], x=out["x"], u=out["u"])
+                        status=out["status"], iters=out["iters"], x=out["x"], u=out["u"],
+                        u0_polish=outp["u0"], x_polish=outp["x"], u_polish=outp["u"], iters_polish=outp["iters"])
     print("rti_cold_start.npz:", x0.shape[0], "instances, iters", out["iters"].min(), "..", out["iters"].max())
 
 

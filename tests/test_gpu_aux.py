@@ -106,7 +106,7 @@ def test_closed_loop_rollout_stays_on_device_and_converges_to_hover():
     xs, us = ro.run(x0, steps, setpoint=(0.0, 0.0, 1.0), yaw=0.0)
     assert xs.shape == (steps + 1, B, 13) and us.shape == (steps, B, 4)
     # the same closed loop through the oracle (plant = the oracle's own ERK interval)
-    c = O.default_config(qp_gamma=0.0)
+    c = O.default_config(qp_gamma=0.0, qp_polish=1)
     yref, ye = O.hover_yref(c)
     for b in (0, 17):
         x = x0[b].copy(); xt = ut = None

@@ -23,8 +23,10 @@ def make_solver(**over):
     return NmpcOcpSolver(_lib.default_config(**over))
 
 
-def oracle_cfg(**over):
-    return O.default_config(qp_gamma=0.0, **over)
+def oracle_cfg(polish=False, **over):
+    """polish=True: the oracle with the same active-set polish as the team kernel (its default);
+    the lane and condensed kernels are plain interior point."""
+    return O.default_config(qp_gamma=0.0, qp_polish=1 if polish else 0, **over)
 
 
 def hover(cfg):
@@ -39,7 +41,7 @@ def test_cold_start_batch_matches_oracle(dist, seed, share, mapping):
     x0 = sample_x0(300, seed, **dist)          # ragged: not a multiple of the wave size
     yref, ye = hover(s.config)
     out = s.solve_batch(x0, yref, ye, want_traj=True)
-    ref = O.solve_batch(oracle_cfg(), x0, yref, ye, want_traj=True)
+    ref = O.solve_batch(oracle_cfg(polish=(mapping == "team")), x0, yref, ye, want_traj=True)
     assert (out["status"] == 0).all() and (ref["status"] == 0).all()
     np.testing.assert_allclose(out["u0"], ref["u0"], rtol=0, atol=TOL_U)
     np.testing.assert_allclose(out["x"], ref["x"], rtol=0, atol=TOL_X)
@@ -47,13 +49,15 @@ def test_cold_start_batch_matches_oracle(dist, seed, share, mapping):
     st = s.stats()
     assert st["batch"] == 300 and st["n_status"][0] == 300
     assert abs(st["iter_mean"] - ref["iters"].mean()) < 0.05
+    if mapping == "team":
+        assert st["n_polished"] >= 290          # the active-set path really ran
 
 
 @pytest.mark.parametrize("mapping", ["lane", "team"])
 def test_per_instance_yref_and_warm_start(mapping):
     """[B,N,17] references + a second RTI from the previous solution (controller.py:419-424)."""
     s = make_solver(flags=1 | (_lib.FLAG_TEAM_MAPPING if mapping == "team" else 0))
-    c = oracle_cfg()
+    c = oracle_cfg(polish=(mapping == "team"))
     B = 96
     x0 = sample_x0(B, 5, **AGGRESSIVE)
     rng = np.random.default_rng(5)
@@ -79,9 +83,10 @@ def test_golden_fixture(mapping):
     g = np.load(Path(__file__).parent / "golden" / "rti_cold_start.npz")
     s = make_solver(flags=1 | (_lib.FLAG_TEAM_MAPPING if mapping == "team" else 0))
     out = s.solve_batch(g["x0"], g["yref"], g["yref_e"], want_traj=True)
+    sfx = "_polish" if mapping == "team" else ""     # the team kernel's default includes the active-set polish
     np.testing.assert_array_equal(out["status"], g["status"])
-    np.testing.assert_allclose(out["u0"], g["u0"], rtol=0, atol=TOL_U)
-    np.testing.assert_allclose(out["x"], g["x"], rtol=0, atol=TOL_X)
+    np.testing.assert_allclose(out["u0"], g["u0" + sfx], rtol=0, atol=TOL_U)
+    np.testing.assert_allclose(out["x"], g["x" + sfx], rtol=0, atol=TOL_X)
 
 
 def test_known_answers_on_gpu():
@@ -105,12 +110,12 @@ def test_status_paths_on_gpu():
     x0 = sample_x0(70, 7, **NEAR_HOVER)
     x0[3, 4] = np.nan                          # one poisoned lane must not hurt its wave
     out = s.solve_batch(x0, yref, ye)
-    ref = O.solve_batch(oracle_cfg(), x0, yref, ye)
+    ref = O.solve_batch(oracle_cfg(polish=True), x0, yref, ye)
     assert out["status"][3] == 1 and (np.delete(out["status"], 3) == 0).all()
     np.testing.assert_array_equal(out["u0"][3], 0.0)        # controller.py:448-450
     np.testing.assert_allclose(np.delete(out["u0"], 3, 0), np.delete(ref["u0"], 3, 0), atol=TOL_U)
     # iteration cap 1: tolerated like acados RTI, result = oracle's one-iteration result
-    s1 = make_solver(qp_iter_max=1)
+    s1 = make_solver(qp_iter_max=1, qp_polish=0)
     o = s1.solve_batch(x0[:3], yref, ye)
     r = O.solve_batch(oracle_cfg(qp_iter_max=1), x0[:3], yref, ye)
     np.testing.assert_array_equal(o["status"], r["status"])
@@ -120,7 +125,7 @@ def test_status_paths_on_gpu():
 def test_single_instance_set_solve_get_surface():
     """The exact call sequence of PositionNMPC.solve (controller.py:412-460)."""
     s = make_solver(max_batch=1)
-    c = oracle_cfg()
+    c = oracle_cfg(polish=True)
     N = s.N
     yref, ye = hover(s.config)
     x0 = sample_x0(1, 9, **AGGRESSIVE)[0]
@@ -143,7 +148,7 @@ def test_single_instance_set_solve_get_surface():
 def test_long_horizon_and_odd_sizes():
     for N, B in ((3, 5), (60, 33)):
         s = make_solver(N=N, max_batch=64)
-        c = oracle_cfg(N=N)
+        c = oracle_cfg(polish=True, N=N)
         yref, ye = hover(s.config)
         x0 = sample_x0(B, N, **AGGRESSIVE)
         out = s.solve_batch(x0, yref, ye)
@@ -169,7 +174,7 @@ def test_full_size_properties_batch_4096():
     out_m = s.solve_batch(x0, np.tile(yref, (4096, 1, 1)), np.tile(ye, (4096, 1)))
     np.testing.assert_array_equal(out_m["u0"], out["u0"])
     idx = np.arange(0, 4096, 16)
-    ref = O.solve_batch(oracle_cfg(), x0[idx], yref, ye)
+    ref = O.solve_batch(oracle_cfg(polish=True), x0[idx], yref, ye)
     np.testing.assert_allclose(out["u0"][idx], ref["u0"], atol=TOL_U)
 
 
@@ -205,7 +210,7 @@ def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
     """SURVEY 8a7 on the GPU: k_cond_ipm (condense -> IPM on dense blocks -> expand) vs the oracle's
     condensed solve, and vs the team kernel on the uncondensed QP (solution invariance, U8)."""
     sc = make_solver(N=N, qp_cond_N=cond_N, flags=_lib.FLAG_CONDENSED_QP | 1, max_batch=128)
-    st = make_solver(N=N, flags=_lib.FLAG_TEAM_MAPPING | 1, max_batch=128)
+    st = make_solver(N=N, flags=_lib.FLAG_TEAM_MAPPING | 1, max_batch=128, qp_polish=0)
     yref, ye = hover(sc.config)
     x0 = sample_x0(100, 4, **AGGRESSIVE)
     oc = sc.solve_batch(x0, yref, ye, want_traj=True)

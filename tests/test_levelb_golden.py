@@ -45,7 +45,7 @@ def test_facade_on_oracle_backend_reproduces_reference_controller(monkeypatch):
 @pytest.mark.gpu
 def test_facade_on_hip_backend_reproduces_reference_controller(monkeypatch):
     monkeypatch.delenv("ROTORS_MPC_PARAMS", raising=False)
-    ctrl = PositionNMPC(load_params())
+    ctrl = PositionNMPC(load_params(), qp_polish=0)     # golden = reference controller on the plain-IPM oracle
     _replay(ctrl, tol=1e-9)
 
 
