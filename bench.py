@@ -39,9 +39,11 @@ def algorithmic_bytes(N: int, esz: int, bcast: bool, traj_out: bool) -> int:
     return b
 
 
-def algorithmic_flops(N: int, n_ipm: float) -> float:
-    """F = N*F_lin + n_ipm*N*F_kkt (dense-equivalent count, nominal)."""
-    return N * 7.7e3 + n_ipm * N * 11.9e3
+def algorithmic_flops(N: int, n_kkt: float) -> float:
+    """F = N*F_lin + n_kkt*N*F_kkt (dense-equivalent count, nominal).  n_kkt = KKT
+    factorise-and-solve rounds: IPM iterations (1 factorisation + 2 solves) plus active-set passes
+    (1 factorisation + 1 solve + 1 adjoint sweep), both priced at F_kkt = 11.9 kflop per stage."""
+    return N * 7.7e3 + n_kkt * N * 11.9e3
 
 
 def cpu_baseline(B_sample: int, N: int):
@@ -170,13 +172,14 @@ def main() -> None:
         n_ipm = st["iter_mean"]
         kern_s = st["ms_solve"] * 1e-3
         alg_b = algorithmic_bytes(N, esz, bcast, args.traj_out)
-        flops = algorithmic_flops(N, n_ipm)
+        n_kkt = n_ipm + st["polish_mean"]
+        flops = algorithmic_flops(N, n_kkt)
         f_peak = FP64_VEC_PEAK_TF if args.dtype == "f64" else FP32_VEC_PEAK_TF
         hbm_alg_gbs = alg_b * B / kern_s / 1e9
         alu_tf = flops * B / kern_s / 1e12
         # streamed solver workspace per solve (kernel table): rows read+written per stage and IPM iteration
         ws_rows = 820 if args.no_share else 420
-        ws_gbs = (n_ipm * N * ws_rows * esz) * B / kern_s / 1e9
+        ws_gbs = (n_kkt * N * ws_rows * esz) * B / kern_s / 1e9
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of the SAME command
         # (tools/rocprof_capture.sh); FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per the
         # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
@@ -193,7 +196,7 @@ def main() -> None:
                     kernel_ms=st["ms_solve"], prepare_ms=st["ms_prepare"], algorithmic_bytes_per_solve=alg_b,
                     workspace_model_gbs=ws_gbs,
                     alu=dict(achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak,
-                             flops_per_solve=flops, n_ipm_mean=n_ipm))
+                             flops_per_solve=flops, n_ipm_mean=n_ipm, n_kkt_rounds_mean=n_kkt))
         line = dict(metric="NMPC SQP-RTI solves/sec (N=20, nx=13, nu=4) at batch=4096 per GPU",
                     value=rate, unit="solves/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=ms_step, device_ms_per_step=dev_ms, higher_is_better=True, scaling="weak",
