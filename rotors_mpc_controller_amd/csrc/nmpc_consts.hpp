@@ -52,6 +52,7 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.polish_passes = g.qp_polish_passes;
     c.polish_budget = g.qp_polish_budget;
     c.polish_mu = (T)g.qp_polish_mu;
+    c.kkt_tol = sizeof(T) == 8 ? (T)1e-9 : (T)1e-5;   // the oracle uses 1e-9; FP32 gradients carry ~1e-6 noise
 }
 
 

@@ -61,7 +61,7 @@ struct Consts {
     T tol_comp, tol_stat, mu0, tau, thr0, thr0_rel;
     // active-set polish (team kernel only; the lane and condensed kernels are plain IPM)
     int polish, polish_passes, polish_budget;
-    T polish_mu;
+    T polish_mu, kkt_tol;   // kkt_tol: relative acceptance tolerance of the active-set KKT check
 };
 
 // SoA workspace: row r of an array is the contiguous run [r*Bp, r*Bp + Bp)

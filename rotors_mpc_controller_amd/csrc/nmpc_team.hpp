@@ -499,11 +499,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
                 T npc;
                 if (pc != T(0)) {                                // multiplier sign of a pinned input
-                    const T tol = T(1e-9) * (T(1) + fabs(g));
+                    const T tol = c.kkt_tol *(T(1) + fabs(g));
                     const bool wrong = (pc < T(0) && g < -tol) || (pc > T(0) && g > tol);
                     npc = wrong ? T(0) : pc;
                 } else {                                         // free input inside its box?
-                    const T tol = T(1e-9) * (T(1) + fabs(lo) + fabs(hi));
+                    const T tol = c.kkt_tol *(T(1) + fabs(lo) + fabs(hi));
                     npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
                 }
                 chg += (npc != pc) ? T(1) : T(0);

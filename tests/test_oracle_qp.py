@@ -213,3 +213,37 @@ def test_warm_start_second_iteration_converges_towards_nlp_solution():
         steps.append(np.abs(un - ut).max())
         xt, ut = xn, un
     assert steps[-1] < 1e-2 * steps[0]
+
+
+# ---------------------------------------------------------------- active-set polish
+@pytest.mark.parametrize("dist,seed", [(NEAR_HOVER, 0), (AGGRESSIVE, 1), (WILD, 2)])
+def test_active_set_polish_returns_the_exact_qp_solution(dist, seed):
+    """qp_polish: an accepted active-set solve satisfies the KKT conditions of the QP, so it must
+    equal the exact (BVLS) solution to rounding -- far tighter than the IPM it replaces."""
+    c = O.default_config(qp_polish=1)
+    yref, ye = O.hover_yref(c)
+    accepted = 0
+    for x0 in sample_x0(24, seed, **dist):
+        xt, ut = cold(c, x0)
+        qp = O.linearize(c, xt, ut, yref, ye)
+        s, dx, du, st = O.qp_solve(c, qp)
+        dxe, due = solve_exact(qp)
+        assert s == 0
+        if st.polished:
+            accepted += 1
+            np.testing.assert_allclose(du, due, rtol=0, atol=1e-10)
+            np.testing.assert_allclose(dx, dxe, rtol=0, atol=1e-10)
+            assert st.res_stat < 1e-9 and st.res_comp < 1e-12      # exact KKT point, true residuals
+            assert (du >= qp["lo"]).all() and (du <= qp["hi"]).all()
+        else:
+            np.testing.assert_allclose(du, due, rtol=0, atol=5e-6)  # fell back to the plain IPM
+    assert accepted >= (24 if dist is NEAR_HOVER else 20)
+
+
+def test_polish_off_is_the_plain_ipm_and_polish_on_needs_fewer_kkt_rounds():
+    yref, ye = O.hover_yref(O.default_config())
+    x0 = sample_x0(64, 3, **AGGRESSIVE)
+    plain = O.solve_batch(O.default_config(qp_polish=0), x0, yref, ye)
+    pol = O.solve_batch(O.default_config(qp_polish=1), x0, yref, ye)
+    assert plain["iters"].min() >= 5 and pol["iters"].mean() < 0.5
+    assert np.abs(plain["u0"] - pol["u0"]).max() < 1e-4          # same solution up to the IPM's accuracy
