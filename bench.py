@@ -100,8 +100,12 @@ def main() -> None:
         raise SystemExit("bench.py needs a GPU: the solver has no CPU path")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = world > 1 or os.environ.get("NMPC_BENCH_FORCE_DIST") == "1"   # the env knob rehearses the RCCL path on 1 GPU
+    if use_dist:
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29531")
+        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
 
     B, N = args.batch, args.horizon
     tdt, npdt, esz = (torch.float64, np.float64, 8) if args.dtype == "f64" else (torch.float32, np.float32, 4)
@@ -125,24 +129,37 @@ def main() -> None:
     else:
         yref = torch.from_numpy(np.tile(yref_h, (B, 1, 1)).astype(npdt)).to(dev).contiguous()
         yref_e = torch.from_numpy(np.tile(yref_e_h, (B, 1)).astype(npdt)).to(dev).contiguous()
-    u0 = torch.zeros(B, 4, dtype=tdt, device=dev)
+    # two command buffers: the RCCL gather of tick i (own stream) overlaps the solve of tick i+1
+    u0s = [torch.zeros(B, 4, dtype=tdt, device=dev) for _ in range(2)]
+    u0 = u0s[0]
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     xo = torch.zeros(B, N + 1, 13, dtype=tdt, device=dev) if args.traj_out else None
     uo = torch.zeros(B, N, 4, dtype=tdt, device=dev) if args.traj_out else None
-    gathered = torch.zeros(world * B, 4, dtype=tdt, device=dev) if world > 1 else None
+    gathered = [torch.zeros(world * B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
+    pending = [None, None]
     stream = torch.cuda.current_stream(dev)
+    tick = [0]
 
     def step():
-        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0.data_ptr(),
+        k = tick[0] & 1
+        tick[0] += 1
+        if use_dist and pending[k] is not None:
+            pending[k].wait()                                   # buffer k's previous gather must have drained
+            pending[k] = None
+        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0s[k].data_ptr(),
                                   status_ptr=status.data_ptr(),
                                   x_out_ptr=xo.data_ptr() if xo is not None else 0,
                                   u_out_ptr=uo.data_ptr() if uo is not None else 0,
                                   stream=stream.cuda_stream)
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, u0)           # RCCL over xGMI
+        if use_dist:                                            # RCCL over xGMI, asynchronous to the next solve
+            pending[k] = dist.all_gather_into_tensor(gathered[k], u0s[k], async_op=True)
 
     def fence():
-        if world > 1:
+        if use_dist:
+            for k in (0, 1):
+                if pending[k] is not None:
+                    pending[k].wait()
+                    pending[k] = None
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -163,7 +180,10 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     st = solver.stats()                                          # HIP events of the LAST timed step
-    u0_h = u0.cpu().numpy().astype(np.float64)
+    u0_h = u0s[(tick[0] - 1) & 1].cpu().numpy().astype(np.float64)
+    if use_dist:                                                 # the gathered block of this rank is its own u0
+        g = gathered[(tick[0] - 1) & 1][rank * B:(rank + 1) * B].cpu().numpy().astype(np.float64)
+        assert np.array_equal(g, u0_h), "all-gather returned a different u0 block"
     status_h = status.cpu().numpy()
 
     if rank == 0:
@@ -216,7 +236,7 @@ def main() -> None:
             line["max_abs_u0_vs_oracle"] = float(np.abs(u0_h[:ns][ok] - ref["u0"][ok]).max())
             line["parity_note"] = "vs build CPU oracle; acados parity unpinned (SURVEY 8c)"
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

@@ -1,9 +1,11 @@
 // nmpc_capi.hip -- HIP kernels (gfx950) and the C ABI of include/rotors_nmpc.h.
 //
-// One MPC instance per wavefront lane; one 64-lane wave per workgroup so that a batch of B
-// instances becomes ceil(B/64) independent workgroups that the dispatcher spreads over all
-// XCDs.  No inter-workgroup communication exists on this path (instances are independent),
-// so no release/acquire protocol is needed.
+// Kernels: k_team_prepare / k_team_ipm (16 lanes per MPC instance, 4 instances per wave, default),
+// k_prepare / k_ipm (one instance per lane), k_cond_ipm (partial-condensing fidelity path) and the
+// element-wise kernels of nmpc_aux.hpp.  Every workgroup is one 64-lane wave, so a batch becomes
+// hundreds to thousands of independent workgroups that the dispatcher spreads over all XCDs; no
+// inter-workgroup communication exists on this path (instances are independent), so no
+// release/acquire protocol is needed.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -86,7 +88,6 @@ struct nmpc_solver {
     bool timed = false;
     // single-instance slot (AcadosOcpSolver.set/get state)
     std::vector<double> sx, su, syref, syref_e, sx0;
-    bool x0_set = false;
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2|4 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
 
@@ -291,10 +292,11 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out;
     const dim3 grid((B + 63) / 64), block(64);
     HIP_TRY(s, hipEventRecord(s->ev[0], st));
-    HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));
     // team-mapped preparation below ~16k instances (few waves otherwise: 0.129 -> 0.041 ms at B = 4096);
     // above, one instance per lane already fills the chip and does no replicated work (B = 65536: 0.32 vs 0.52 ms)
     const bool team_only = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP) && B <= 16384;
+    if (!((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP)))
+        HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // only k_team_ipm writes it
     if (team_only)
         hipLaunchKernelGGL(k_team_prepare<T>, dim3((B + 3) / 4), block, 0, st, c, w, in, B);
     else

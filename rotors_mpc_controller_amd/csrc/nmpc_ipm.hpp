@@ -99,12 +99,6 @@ NMPC_HD void lane_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> 
     }
 }
 
-// per-pair Newton quantities shared by the sweeps
-template <class T>
-struct PairStep {
-    T dl, du;   // delta lambda_l, delta lambda_u
-};
-
 template <class T>
 NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out, int lane)
 {

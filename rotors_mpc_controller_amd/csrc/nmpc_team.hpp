@@ -480,37 +480,50 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T pi_r = QdNr * xh + NMPC_LD(w.qr, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
             p = 0;
-            for (int k = N - 1; k >= 0; k--) {
-                if (!SHARED) load_stage(k);
-                T *ivk = tIV + k * IV_ROWS;
-                const T ul = NMPC_LD(w.ul, k * NU + j), uj = ivk[12 + j], pc = ivk[16 + j];
-                const T rk = NMPC_LD(w.qr, k * QR_ROWS + NX + j), q_r = NMPC_LD(w.qr, k * QR_ROWS + rr);
-                const T xk = k > 0 ? tLM[k * TLM_ROWS + 66 + rr] : T(0);
-                sXh[p * 16 + r] = pi_r;
-                NMPC_WSYNC();
-                const T lo = lbj - ul, hi = ubj - ul;
-                const T vpin = pc < T(0) ? lo : hi;
-                const T ue = pc != T(0) ? vpin : uj;            // pinned inputs sit exactly on the bound
-                T g = Rdj * ue + rk, an = 0;
-                NMPC_UNROLL for (int l = 0; l < NX; l++) {
-                    const T pl = sXh[p * 16 + l];
-                    g += sB[l * 4 + j] * pl;
-                    an += Acol[l] * pl;
+            constexpr int CH = 8;     // stage scalars are fetched a chunk at a time (see the final sweep)
+            for (int k0 = N - 1; k0 >= 0; k0 -= CH) {
+                T c_ul[CH], c_uj[CH], c_pc[CH], c_rk[CH], c_qr[CH], c_xk[CH];
+                NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                    const int k = (k0 - i > 0) ? k0 - i : 0;
+                    const T *ivk = tIV + k * IV_ROWS;
+                    c_ul[i] = NMPC_LD(w.ul, k * NU + j); c_uj[i] = ivk[12 + j]; c_pc[i] = ivk[16 + j];
+                    c_rk[i] = NMPC_LD(w.qr, k * QR_ROWS + NX + j); c_qr[i] = NMPC_LD(w.qr, k * QR_ROWS + rr);
+                    c_xk[i] = tLM[k * TLM_ROWS + 66 + rr];
                 }
-                T npc;
-                if (pc != T(0)) {                                // multiplier sign of a pinned input
-                    const T tol = c.kkt_tol *(T(1) + fabs(g));
-                    const bool wrong = (pc < T(0) && g < -tol) || (pc > T(0) && g > tol);
-                    npc = wrong ? T(0) : pc;
-                } else {                                         // free input inside its box?
-                    const T tol = c.kkt_tol *(T(1) + fabs(lo) + fabs(hi));
-                    npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
+                NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                    const int k = k0 - i;
+                    if (k >= 0) {
+                        if (!SHARED) load_stage(k);
+                        T *ivk = tIV + k * IV_ROWS;
+                        const T ul = c_ul[i], uj = c_uj[i], pc = c_pc[i], rk = c_rk[i], q_r = c_qr[i];
+                        const T xk = k > 0 ? c_xk[i] : T(0);
+                        sXh[p * 16 + r] = pi_r;
+                        NMPC_WSYNC();
+                        const T lo = lbj - ul, hi = ubj - ul;
+                        const T vpin = pc < T(0) ? lo : hi;
+                        const T ue = pc != T(0) ? vpin : uj;            // pinned inputs sit exactly on the bound
+                        T g = Rdj * ue + rk, an = 0;
+                        NMPC_UNROLL for (int l = 0; l < NX; l++) {
+                            const T pl = sXh[p * 16 + l];
+                            g += sB[l * 4 + j] * pl;
+                            an += Acol[l] * pl;
+                        }
+                        T npc;
+                        if (pc != T(0)) {                                // multiplier sign of a pinned input
+                            const T tol = c.kkt_tol *(T(1) + fabs(g));
+                            const bool wrong = (pc < T(0) && g < -tol) || (pc > T(0) && g > tol);
+                            npc = wrong ? T(0) : pc;
+                        } else {                                         // free input inside its box?
+                            const T tol = c.kkt_tol *(T(1) + fabs(lo) + fabs(hi));
+                            npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
+                        }
+                        chg += (npc != pc) ? T(1) : T(0);
+                        nanf += (ue == ue && g == g && an == an) ? T(0) : T(1);
+                        if (cmpl && pol2 && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
+                        pi_r = Qdr * xk + q_r + an;
+                        p ^= 1;
+                    }
                 }
-                chg += (npc != pc) ? T(1) : T(0);
-                nanf += (ue == ue && g == g && an == an) ? T(0) : T(1);
-                if (cmpl && pol2 && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
-                pi_r = Qdr * xk + q_r + an;
-                p ^= 1;
             }
             if (cmpl) { sRed[20 + j] = chg; sRed[24 + j] = nanf; }
             __syncthreads();
@@ -673,24 +686,40 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         bool bad = false;
         int p = 0;
         const bool upd = (status == 0 || status == 2);
-        for (int k = 0; k < N; k++) {
-            if (!SHARED) load_stage(k);
-            const T u = tIV[k * IV_ROWS + (from_ua ? 12 : 0) + j];
-            if (cmpl) sDr[p * 4 + j] = u;
-            sXh[p * 16 + r] = dx;
-            NMPC_WSYNC();
-            T du[NU];
-            NMPC_UNROLL for (int i = 0; i < NU; i++) { du[i] = sDr[p * 4 + i]; bad |= !(du[i] == du[i]); }
-            T a = b_r;
-            a += (rr < 3) ? dx + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? dx : T(0));
-            NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
-            NMPC_UNROLL for (int i = 0; i < NU; i++) a += Brow[i] * du[i];
-            dx = a;
-            if (upd && valid) {
-                if (cmpl) NMPC_ST(w.ul, k * NU + j, NMPC_LD(w.ul, k * NU + j) + u);
-                if (rowl) NMPC_ST(w.xl, (k + 1) * NX + rr, NMPC_LD(w.xl, (k + 1) * NX + rr) + dx);
+        // loads of a chunk of stages are issued together: the read-modify-write of xl/ul may alias as
+        // far as the compiler knows, and one exposed global round trip per stage dominated this sweep
+        constexpr int CH = 8;
+        const int uoff = (from_ua ? 12 : 0) + j;
+        for (int k0 = 0; k0 < N; k0 += CH) {
+            T uv[CH], ulv[CH], xlv[CH];
+            NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                const int k = (k0 + i < N) ? k0 + i : N - 1;
+                uv[i] = tIV[k * IV_ROWS + uoff];
+                ulv[i] = NMPC_LD(w.ul, k * NU + j);
+                xlv[i] = NMPC_LD(w.xl, (k + 1) * NX + rr);
             }
-            p ^= 1;
+            NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                const int k = k0 + i;
+                if (k < N) {
+                    if (!SHARED) load_stage(k);
+                    const T u = uv[i];
+                    if (cmpl) sDr[p * 4 + j] = u;
+                    sXh[p * 16 + r] = dx;
+                    NMPC_WSYNC();
+                    T du[NU];
+                    NMPC_UNROLL for (int ii = 0; ii < NU; ii++) { du[ii] = sDr[p * 4 + ii]; bad |= !(du[ii] == du[ii]); }
+                    T a = b_r;
+                    a += (rr < 3) ? dx + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? dx : T(0));
+                    NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
+                    NMPC_UNROLL for (int ii = 0; ii < NU; ii++) a += Brow[ii] * du[ii];
+                    dx = a;
+                    if (upd && valid) {
+                        if (cmpl) NMPC_ST(w.ul, k * NU + j, ulv[i] + u);
+                        if (rowl) NMPC_ST(w.xl, (k + 1) * NX + rr, xlv[i] + dx);
+                    }
+                    p ^= 1;
+                }
+            }
         }
         // NaN anywhere in the step poisons the instance: reduce the flag over the team
         sXh[r] = (dx == dx && !bad) ? T(0) : T(1);
@@ -762,22 +791,38 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     const T Wqr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Wq[i] : v; return v; }();
     const T WqNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.WqN[i] : v; return v; }();
     const T Wrj = sel4(c.Wr, j);
-    // staging and cost gradients (U4)
-    for (int k = 0; k <= N; k++) {
-        const T xk = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0[rr];   // stage 0 is pinned to x0
-        if (rowl && valid) NMPC_ST(w.xl, k * NX + rr, xk);
-        if (k < N) {
-            const T uk = warm ? ui[(size_t)k * NU + j] : T(0);
-            if (valid) {
-                if (rowl) NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xk - yr[(size_t)k * NY + rr]));
+    // staging and cost gradients (U4).  Loads are issued a chunk of stages at a time before any store:
+    // the workspace stores may alias the inputs as far as the compiler knows, and a load-store-load
+    // chain per stage costs one HBM round trip each (21 of them dominated this kernel).
+    const T x0r = x0[rr];
+    constexpr int CH = 8;
+    for (int k0 = 0; k0 < N; k0 += CH) {
+        T xv[CH], uv[CH], yx[CH], yu[CH];
+        NMPC_UNROLL for (int i = 0; i < CH; i++) {
+            const int k = (k0 + i < N) ? k0 + i : N - 1;
+            xv[i] = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r;     // stage 0 is pinned to x0
+            uv[i] = warm ? ui[(size_t)k * NU + j] : T(0);
+            yx[i] = yr[(size_t)k * NY + rr];
+            yu[i] = yr[(size_t)k * NY + NX + j];
+        }
+        NMPC_UNROLL for (int i = 0; i < CH; i++) {
+            const int k = k0 + i;
+            if (k < N && valid) {
+                if (rowl) {
+                    NMPC_ST(w.xl, k * NX + rr, xv[i]);
+                    NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
+                }
                 if (cmpl) {
-                    NMPC_ST(w.ul, k * NU + j, uk);
-                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uk - yr[(size_t)k * NY + NX + j]));
+                    NMPC_ST(w.ul, k * NU + j, uv[i]);
+                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
                 }
             }
-        } else if (rowl && valid) {
-            NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xk - ye[rr]));
         }
+    }
+    if (rowl && valid) {
+        const T xN = warm ? xi[(size_t)N * NX + rr] : x0r;
+        NMPC_ST(w.xl, N * NX + rr, xN);
+        NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xN - ye[rr]));
     }
     // linearisation: one interval if the cold start lets all stages share it
     const int Ns = c.shared ? 1 : N;
