@@ -83,6 +83,7 @@ def main() -> None:
     ap.add_argument("--mapping", choices=["team", "lane"], default="team",
                     help="QP phase: 16 lanes per instance (team) or one instance per lane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--polish-ckpt", type=int, default=None, help="override nmpc_config.qp_polish_ckpt")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
 
@@ -115,6 +116,8 @@ def main() -> None:
                               | (_lib.FLAG_TEAM_MAPPING if args.mapping == "team" else 0))
     if args.dtype == "f32":
         cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
+    if args.polish_ckpt is not None:
+        cfg.update(qp_polish_ckpt=args.polish_ckpt)
     solver = NmpcOcpSolver(cfg)
     hover = cfg.mass * cfg.gravity / 4.0
     seed = 0 if world == 1 else 100 + rank                      # config 2 / config 4

@@ -89,6 +89,10 @@ typedef struct nmpc_config {
     int32_t qp_polish_passes;  /* active-set corrections per attempt */
     int32_t qp_polish_budget;  /* no new attempt after this many passes */
     double qp_polish_mu;       /* first attempt when mu <= this (>= mu0: before any IPM iteration), then every 100x below */
+    int32_t qp_polish_ckpt;    /* leading stages whose Riccati state (P_k, p_k) an active-set pass checkpoints: the next
+                                  pass refactorises only stages <= the highest stage whose pin set changed when that
+                                  lies inside this window, else the whole horizon.  0 = always the whole horizon      */
+    int32_t reserved_;
 } nmpc_config;
 
 typedef struct nmpc_stats {

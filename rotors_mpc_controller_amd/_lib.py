@@ -40,7 +40,7 @@ class NmpcConfig(C.Structure):
         ("qp_tau", C.c_double), ("qp_thr0", C.c_double), ("qp_thr0_rel", C.c_double),
         ("dtype", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_uint32),
         ("qp_polish", C.c_int32), ("qp_polish_passes", C.c_int32), ("qp_polish_budget", C.c_int32),
-        ("qp_polish_mu", C.c_double),
+        ("qp_polish_mu", C.c_double), ("qp_polish_ckpt", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def update(self, **over) -> "NmpcConfig":

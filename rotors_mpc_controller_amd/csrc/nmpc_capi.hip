@@ -75,7 +75,7 @@ struct nmpc_solver {
     int Bp = 0;
     size_t esz = 8;
     // device workspace (element type = cfg.dtype)
-    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *cond = nullptr;
+    void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *tP = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
@@ -156,6 +156,13 @@ void nmpc_default_config(nmpc_config *c)
     c->qp_polish_passes = 5;
     c->qp_polish_budget = 8;
     c->qp_polish_mu = 1.0;
+    c->qp_polish_ckpt = 12;
+    c->reserved_ = 0;
+}
+
+static int ckpt_stages(const nmpc_config &g)
+{
+    return g.qp_polish_ckpt < 0 ? 0 : (g.qp_polish_ckpt > g.N - 1 ? g.N - 1 : g.qp_polish_ckpt);
 }
 
 static int alloc_ws(nmpc_solver *s)
@@ -165,7 +172,9 @@ static int alloc_ws(nmpc_solver *s)
         {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
         {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bp * e},
         {&s->iv, N * IV_ROWS * Bp * e},
-        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bp : 1) * e}, {(void **)&s->d_iters, Bp * sizeof(int32_t)},
+        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bp : 1) * e},
+        {&s->tP, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bp : 1) * e},
+        {(void **)&s->d_iters, Bp * sizeof(int32_t)},
         {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)}};
     for (auto &x : a) {
         HIP_TRY(s, hipMalloc(x.p, x.n));
@@ -256,7 +265,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->d_npol, s->cond, s->tAB, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -314,6 +323,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         TeamWork<T> tw;
         tw.tLM = (T *)s->LM;
         tw.tIV = (T *)s->iv;
+        tw.tP = (s->cfg.qp_polish && c.polish_ckpt > 0) ? (T *)s->tP : nullptr;
         // teams per wave: 4 fills the lanes; fewer (half-empty waves) when the batch alone cannot
         // put two waves on every SIMD, so that LDS/memory latency still has something to hide behind
         int tpw = s->team_tpw;

@@ -51,6 +51,7 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.polish = g.qp_polish;
     c.polish_passes = g.qp_polish_passes;
     c.polish_budget = g.qp_polish_budget;
+    c.polish_ckpt = g.qp_polish_ckpt < 0 ? 0 : (g.qp_polish_ckpt > g.N - 1 ? g.N - 1 : g.qp_polish_ckpt);
     c.polish_mu = (T)g.qp_polish_mu;
     c.kkt_tol = sizeof(T) == 8 ? (T)1e-9 : (T)1e-5;   // the oracle uses 1e-9; FP32 gradients carry ~1e-6 noise
 }

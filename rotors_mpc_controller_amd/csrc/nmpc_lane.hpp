@@ -60,7 +60,7 @@ struct Consts {
     T rx[NU], ry[NU], rz[NU];
     T tol_comp, tol_stat, mu0, tau, thr0, thr0_rel;
     // active-set polish (team kernel only; the lane and condensed kernels are plain IPM)
-    int polish, polish_passes, polish_budget;
+    int polish, polish_passes, polish_budget, polish_ckpt;
     T polish_mu, kkt_tol;   // kkt_tol: relative acceptance tolerance of the active-set KKT check
 };
 

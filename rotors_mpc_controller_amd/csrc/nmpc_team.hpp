@@ -18,6 +18,12 @@
 //   tLM [inst][stage][80] : M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | xhat (13) | pad
 //   tIV [inst][stage][20] : u | lam_l | lam_u | u_aff | du   (4 each); during an active-set pass the last
 //                           two hold the candidate inputs and the pin codes (-1 lower, 0 free, +1 upper)
+//   tP  [inst][1 + ckpt][13][14] : (P_k, p_k), k = 1..ckpt, as left by an active-set pass.  The factorisation
+//                           of stage k depends on the pins of stages >= k only, so the next pass restarts its
+//                           backward sweep at the highest stage whose pin set changed - when that lies in the
+//                           checkpointed window (saturation sits in the first stages of the horizon) - instead
+//                           of at N-1.  The window bounds the store traffic: 1.4 KB per stage and instance
+//                           through a 64 B/clk store path cost 7 % of the sweep when every stage was kept.
 // Inputs of the stage matrices come from the SoA workspace written by k_prepare.
 #pragma once
 
@@ -29,6 +35,8 @@ constexpr int TEAM = 16;            // lanes per instance (one DPP row)
 constexpr int TEAMS_PER_WAVE = 4;
 constexpr int TLM_ROWS = 80;       // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad
 constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
+constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
+constexpr int TP_ROWS = NX * TP_ROW;
 // LDS carve per team, in elements of T
 constexpr int L_AD = 0;             // [16][8]   rows of the dense A columns
 constexpr int L_B = L_AD + 128;     // [16][4]
@@ -54,6 +62,7 @@ template <class T>
 struct TeamWork {
     T *tLM;
     T *tIV;
+    T *tP;     // [inst][1 + ckpt][13][14] Riccati checkpoints of the active-set passes, or null
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -140,6 +149,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     T *sHg = S + L_HG, *sMc = S + L_MC, *sD = S + L_D, *sY = S + L_Y, *sXh = S + L_XH, *sDr = S + L_DR;
     T *sRed = S + L_RED, *sZ = S + L_Z;
     T *tLM = tw.tLM + (size_t)inst * N * TLM_ROWS, *tIV = tw.tIV + (size_t)inst * N * IV_ROWS;
+    const int ckpt = c.polish_ckpt;       // checkpoints exist for stages 1..ckpt
+    T *tP = tw.tP ? tw.tP + (size_t)inst * (ckpt + 1) * TP_ROWS : nullptr;
+    const int nteams = blockDim.x >> 4;
 
     // the two (a,b) entries of the packed 7x7 block this lane computes in the P update
     int za0 = 0, zb0 = 0, za1 = 0, zb1 = 0;
@@ -204,6 +216,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     NMPC_PROF_BEGIN
     T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu;
     int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
+    int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
     // per-team mode: interior point iteration, active-set (polish) pass, or finished
     enum { M_IPM = 0, M_POL = 1, M_DONE = 2 };
     int mode = M_IPM;
@@ -216,7 +229,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (mode == M_IPM) {
             if (!(mu == mu)) { status = 1; mode = M_DONE; }
             else if (mu <= c.tol_comp && rho <= c.tol_stat) mode = M_DONE;
-            else if (c.polish && mu <= pol_mu && npol < c.polish_budget) { mode = M_POL; pass_in_attempt = 0; }
+            else if (c.polish && mu <= pol_mu && npol < c.polish_budget) { mode = M_POL; pass_in_attempt = 0; k_top = N - 1; }
             else if (it >= c.iter_max) { status = 2; mode = M_DONE; }
         }
         if (__ballot(mode != M_DONE) == 0) break;
@@ -224,18 +237,35 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         const bool act = mode != M_DONE;  // frozen teams keep computing but never store
         const bool st_ok = act && valid;
         if (ipm) it++;
+        // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
+        int ks = N - 1;
+        if (tP) {
+            if (r == 0) sRed[28] = (T)(act ? (ipm ? N - 1 : k_top) : -1);
+            __syncthreads();
+            ks = 0;
+            for (int t = 0; t < nteams; t++) {
+                const int kt = (int)smem[t * TEAM_LDS + L_RED + 28];
+                ks = kt > ks ? kt : ks;
+            }
+        }
 
         // ================= sweep A: backward factorisation, affine right-hand side
         T Prow[NX], pv;
-        NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = (cc == rr) ? QdNr : T(0);
-        pv = NMPC_LD(w.qr, N * QR_ROWS + rr);
+        if (ks == N - 1) {
+            NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = (cc == rr) ? QdNr : T(0);
+            pv = NMPC_LD(w.qr, N * QR_ROWS + rr);
+        } else {                      // resume from the checkpoint an earlier active-set pass left
+            const T *cp = tP + ((size_t)(ks + 1) * NX + rr) * TP_ROW;
+            NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = cp[cc];
+            pv = cp[NX];
+        }
         bool ok = true, nanp = false;
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        T n_ul = NMPC_LD(w.ul, (N - 1) * NU + j), n_u = tIV[(N - 1) * IV_ROWS + j],
-          n_ll = tIV[(N - 1) * IV_ROWS + 4 + j], n_lu = tIV[(N - 1) * IV_ROWS + 8 + j],
-          n_pc = tIV[(N - 1) * IV_ROWS + 16 + j],
-          n_rk = NMPC_LD(w.qr, (N - 1) * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, (N - 1) * QR_ROWS + rr);
-        for (int k = N - 1; k >= 0; k--) {
+        T n_ul = NMPC_LD(w.ul, ks * NU + j), n_u = tIV[ks * IV_ROWS + j],
+          n_ll = tIV[ks * IV_ROWS + 4 + j], n_lu = tIV[ks * IV_ROWS + 8 + j],
+          n_pc = tIV[ks * IV_ROWS + 16 + j],
+          n_rk = NMPC_LD(w.qr, ks * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, ks * QR_ROWS + rr);
+        for (int k = ks; k >= 0; k--) {
             if (!SHARED) load_stage(k);
             T *lmk = tLM + k * TLM_ROWS;
             const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
@@ -398,6 +428,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     Prow[cc] = a;
                 }
                 pv = pvn;
+                if (tP && k <= ckpt && pol && st_ok && rowl) {
+                    T *cp = tP + ((size_t)k * NX + rr) * TP_ROW;
+                    NMPC_UNROLL for (int cc = 0; cc < NX; cc++) cp[cc] = Prow[cc];
+                    cp[NX] = pv;
+                }
             }
             NMPC_WSYNC();
         }
@@ -479,6 +514,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (__ballot(pol2) != 0) {
             T pi_r = QdNr * xh + NMPC_LD(w.qr, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
+            int kchg = -1;           // highest stage whose pin set this check changes
             p = 0;
             constexpr int CH = 8;     // stage scalars are fetched a chunk at a time (see the final sweep)
             for (int k0 = N - 1; k0 >= 0; k0 -= CH) {
@@ -518,6 +554,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
                         }
                         chg += (npc != pc) ? T(1) : T(0);
+                        kchg = (npc != pc && kchg < 0) ? k : kchg;
                         nanf += (ue == ue && g == g && an == an) ? T(0) : T(1);
                         if (cmpl && pol2 && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
                         pi_r = Qdr * xk + q_r + an;
@@ -525,9 +562,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                 }
             }
-            if (cmpl) { sRed[20 + j] = chg; sRed[24 + j] = nanf; }
+            if (cmpl) { sRed[20 + j] = chg; sRed[24 + j] = nanf; sRed[28 + j] = (T)kchg; }
             __syncthreads();
             chg = sRed[20] + sRed[21] + sRed[22] + sRed[23];
+            kchg = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
             nanf = sRed[24] + sRed[25] + sRed[26] + sRed[27];
             T xn = 0;                                            // NaN in any xhat row poisons the pass
             sXh[r] = nanf;
@@ -538,6 +576,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 pass_in_attempt++;
                 if (!pol_fail && xn == T(0) && chg == T(0)) { mode = M_DONE; from_ua = true; mu = 0; rho = 0; }
                 else if (pol_fail || !(xn == T(0)) || pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
+                else k_top = kchg < ckpt ? kchg : N - 1;
             }
             __syncthreads();
         }

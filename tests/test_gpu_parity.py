@@ -221,3 +221,26 @@ def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
     np.testing.assert_allclose(oc["x"], ref["x"], rtol=0, atol=TOL_X)
     np.testing.assert_allclose(oc["u0"], ot["u0"], rtol=0, atol=TOL_U)
     np.testing.assert_allclose(oc["u"], ot["u"], rtol=0, atol=TOL_X)
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_riccati_checkpoint_restart_is_transparent(share):
+    """qp_polish_ckpt only decides where an active-set pass resumes its backward sweep: the stages it
+    skips would reproduce the factors already stored, so every window size returns the same solution
+    (and the same pass counts) as full sweeps, and all of them match the oracle's full sweeps."""
+    x0 = sample_x0(512, 11, **AGGRESSIVE)
+    outs = {}
+    for ck in (0, 1, 3, 12, 19):
+        s = make_solver(flags=(1 if share else 0) | _lib.FLAG_TEAM_MAPPING, qp_polish_ckpt=ck)
+        yref, ye = hover(s.config)
+        outs[ck] = s.solve_batch(x0, yref, ye, want_traj=True)
+        st = s.stats()
+        outs[ck]["polish"] = (st["polish_mean"], st["polish_max"], st["n_polished"])
+    assert outs[0]["polish"][1] >= 3                         # the batch really needs several passes
+    for ck in (1, 3, 12, 19):
+        assert outs[ck]["polish"] == outs[0]["polish"]
+        assert np.array_equal(outs[ck]["status"], outs[0]["status"])
+        np.testing.assert_allclose(outs[ck]["u"], outs[0]["u"], rtol=0, atol=1e-12)
+        np.testing.assert_allclose(outs[ck]["x"], outs[0]["x"], rtol=0, atol=1e-12)
+    ref = O.solve_batch(oracle_cfg(polish=True), x0, yref, ye)
+    np.testing.assert_allclose(outs[12]["u0"], ref["u0"], rtol=0, atol=TOL_U)
