@@ -455,8 +455,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) { nM[i] = lmn[rr * 4 + i]; nm[i] = lmn[62 + i]; }
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j];
+            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_pc = ivn[16 + j];
         };
+        // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
+        // which this sweep sees by itself; only a pass with pins (or a violation to correct) needs sweep C
+        T dirty = 0;
         prefetch_fwd(0);
         for (int k = 0; k < N; k++) {
             if (!SHARED) load_stage(k);
@@ -464,7 +467,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T Lf[10], uh[NU];
             NMPC_UNROLL for (int i = 0; i < NU; i++) { sY[p * 64 + r * 4 + i] = nM[i] * xh; uh[i] = nm[i]; }
             NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = nLf[i];
-            const T ul = n_ul, u = n_uu, ll = n_l2, lu = n_l3;
+            const T ul = n_ul, u = n_uu, ll = n_l2, lu = n_l3, pc = n_pc;
             sXh[p * 16 + r] = xh;
             if (k + 1 < N) prefetch_fwd(k + 1);
             NMPC_WSYNC();
@@ -478,6 +481,12 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
                 const T uj = sel4(uh, j);
                 if (cmpl && st_ok2) ivk[12 + j] = uj;
+                {
+                    const T lo = lbj - ul, hi = ubj - ul;
+                    const T tol = c.kkt_tol * (T(1) + fabs(lo) + fabs(hi));
+                    const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
+                    dirty += clean ? T(0) : T(1);
+                }
                 const T d = uj - u;
                 const T dla = -ll - pr.kl * d, dua = -lu + pr.ku * d;
                 // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
@@ -496,10 +505,21 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             p ^= 1;
         }
         NMPC_STAMP(1)
-        if (cmpl) { sRed[4 + j] = rmax; sRed[8 + j] = s2; }
+        if (pol2 && rowl && valid) tLM[66 + rr] = xh;     // xhat_N parks in the unused xhat_0 slot (final sweep)
+        if (cmpl) { sRed[4 + j] = rmax; sRed[8 + j] = s2; sRed[j] = dirty; }
         __syncthreads();
         rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
         s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
+        dirty = sRed[0] + sRed[1] + sRed[2] + sRed[3] + ((xh == xh) ? T(0) : T(1));
+        sXh[r] = dirty;                                   // a NaN in any xhat_N row marks the whole team
+        __syncthreads();
+        NMPC_UNROLL for (int l = 0; l < NX; l++) dirty += sXh[l];
+        const bool need_c = pol2 && (pol_fail || !(dirty == T(0)));
+        if (pol2 && !need_c) {                            // clean pass: the unconstrained solve is the QP solution
+            npol++;
+            pass_in_attempt++;
+            mode = M_DONE; from_ua = true; mu = 0; rho = 0;
+        }
         T sigmu;
         {
             const T aaff = T(1) / rmax;
@@ -511,7 +531,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
 
         // ================= sweep C (teams in an active-set pass): costates by the adjoint recursion,
         // KKT check of the pinned solve, corrected active set (primal-dual active-set step)
-        if (__ballot(pol2) != 0) {
+        if (__ballot(need_c) != 0) {
             T pi_r = QdNr * xh + NMPC_LD(w.qr, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
             int kchg = -1;           // highest stage whose pin set this check changes
@@ -556,7 +576,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         chg += (npc != pc) ? T(1) : T(0);
                         kchg = (npc != pc && kchg < 0) ? k : kchg;
                         nanf += (ue == ue && g == g && an == an) ? T(0) : T(1);
-                        if (cmpl && pol2 && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
+                        if (cmpl && need_c && valid) { ivk[16 + j] = npc; ivk[12 + j] = ue; }
                         pi_r = Qdr * xk + q_r + an;
                         p ^= 1;
                     }
@@ -571,7 +591,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             sXh[r] = nanf;
             __syncthreads();
             NMPC_UNROLL for (int l = 0; l < NX; l++) xn += sXh[l];
-            if (pol2) {
+            if (need_c) {
                 npol++;
                 pass_in_attempt++;
                 if (!pol_fail && xn == T(0) && chg == T(0)) { mode = M_DONE; from_ua = true; mu = 0; rho = 0; }
@@ -720,6 +740,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
 
     NMPC_STAMP(5)
     // ---- final sweep: state rollout from the inputs, full SQP step (U1)
+    T u0_new = 0;
+    bool outputs_done = false;
     {
         T dx = 0;
         bool bad = false;
@@ -729,6 +751,35 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // far as the compiler knows, and one exposed global round trip per stage dominated this sweep
         constexpr int CH = 8;
         const int uoff = (from_ua ? 12 : 0) + j;
+        // every instance of this wave ended on an accepted active-set pass: its forward sweep already
+        // left xhat_k (the same recursion on the same inputs), so the step is applied stage-parallel
+        const bool fast = __ballot(valid && !from_ua) == 0;
+        if (fast) {
+            // the workspace iterate (xl, ul) is not read again after this kernel: the new iterate goes
+            // straight to the caller's arrays (13- and 4-element runs per team), or nowhere but u0
+            u0_new = NMPC_LD(w.ul, j) + tIV[uoff];
+            if (out.x_out || out.u_out) {
+                for (int k0 = 0; k0 <= N; k0 += CH) {
+                    T uv[CH], ulv[CH], xlv[CH], xhv[CH];
+                    NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                        const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
+                        uv[i] = tIV[ku * IV_ROWS + uoff];
+                        ulv[i] = NMPC_LD(w.ul, ku * NU + j);
+                        xlv[i] = NMPC_LD(w.xl, k * NX + rr);
+                        xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot
+                    }
+                    NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                        const int k = k0 + i;
+                        if (k <= N && valid) {
+                            if (out.x_out && rowl)
+                                out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = xlv[i] + (k > 0 ? xhv[i] : T(0));
+                            if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = ulv[i] + uv[i];
+                        }
+                    }
+                }
+            }
+            outputs_done = true;
+        } else
         for (int k0 = 0; k0 < N; k0 += CH) {
             T uv[CH], ulv[CH], xlv[CH];
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -760,19 +811,24 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
             }
         }
-        // NaN anywhere in the step poisons the instance: reduce the flag over the team
-        sXh[r] = (dx == dx && !bad) ? T(0) : T(1);
-        __syncthreads();
-        T nb = 0;
-        NMPC_UNROLL for (int l = 0; l < NX; l++) nb += sXh[l];
-        if (nb > T(0) && upd) status = 1;
+        if (!fast) {
+            // NaN anywhere in the step poisons the instance: reduce the flag over the team
+            // (an accepted active-set pass has been checked already)
+            sXh[r] = (dx == dx && !bad) ? T(0) : T(1);
+            __syncthreads();
+            T nb = 0;
+            NMPC_UNROLL for (int l = 0; l < NX; l++) nb += sXh[l];
+            if (nb > T(0) && upd) status = 1;
+            u0_new = NMPC_LD(w.ul, j);
+        }
     }
     NMPC_STAMP(6)
     NMPC_PROF_END(w)
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     if (valid) {
         if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; if (w.npol) w.npol[inst] = from_ua ? npol : -npol; }   // > 0: accepted active-set solution
-        if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? NMPC_LD(w.ul, j) : T(0);   // controller.py:448-452
+        if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? u0_new : T(0);   // controller.py:448-452
+        if (outputs_done) return;
         if (out.x_out && rowl) {
             for (int k = 0; k <= N; k++) out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = NMPC_LD(w.xl, k * NX + rr);
         }
