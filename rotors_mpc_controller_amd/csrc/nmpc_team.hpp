@@ -260,25 +260,31 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             pv = cp[NX];
         }
         bool ok = true, nanp = false;
+        // a wave whose live teams are all in active-set passes skips the barrier terms (wave-uniform)
+        const bool any_ipm = __ballot(ipm) != 0;
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        T n_ul = NMPC_LD(w.ul, ks * NU + j), n_u = tIV[ks * IV_ROWS + j],
-          n_ll = tIV[ks * IV_ROWS + 4 + j], n_lu = tIV[ks * IV_ROWS + 8 + j],
+        T n_ul = NMPC_LD(w.ul, ks * NU + j), n_u = 0, n_ll = 0, n_lu = 0,
           n_pc = tIV[ks * IV_ROWS + 16 + j],
           n_rk = NMPC_LD(w.qr, ks * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, ks * QR_ROWS + rr);
+        if (any_ipm) { n_u = tIV[ks * IV_ROWS + j]; n_ll = tIV[ks * IV_ROWS + 4 + j]; n_lu = tIV[ks * IV_ROWS + 8 + j]; }
         for (int k = ks; k >= 0; k--) {
             if (!SHARED) load_stage(k);
             T *lmk = tLM + k * TLM_ROWS;
             const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
             if (k > 0) {
                 const T *ivn = tIV + (k - 1) * IV_ROWS;
-                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; n_pc = ivn[16 + j];
+                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
                 n_rk = NMPC_LD(w.qr, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_LD(w.qr, (k - 1) * QR_ROWS + rr);
             }
             {   // IPM: barrier terms.  Active-set pass: no barrier, pinned inputs are taken out of B
                 // (free mask) and enter through b (pinned value); their own row keeps R_jj so u_j = bound.
                 const T lo = lbj - ul, hi = ubj - ul;
-                const Pair<T> pr(u, ll, lu, lo, hi);
-                const T sg = pol ? T(0) : pr.kl + pr.ku;
+                T sg = 0;
+                if (any_ipm) {
+                    const Pair<T> pr(u, ll, lu, lo, hi);
+                    sg = pol ? T(0) : pr.kl + pr.ku;
+                }
                 const bool pinned = pol && pc != T(0);
                 const T vpin = pc < T(0) ? lo : hi;
                 if (cmpl) {
@@ -450,12 +456,13 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // ================= sweep B: forward affine solve
         T xh = 0, rmax = T(1), s2 = 0;   // rmax: largest inverse step length, floor 1 => alpha_aff <= 1
         int p = 0;
-        T nM[NU], nLf[10], nm[NU], n_uu, n_l2, n_l3;
+        T nM[NU], nLf[10], nm[NU], n_uu = 0, n_l2 = 0, n_l3 = 0;
         auto prefetch_fwd = [&](int k) {
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) { nM[i] = lmn[rr * 4 + i]; nm[i] = lmn[62 + i]; }
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_pc = ivn[16 + j];
+            n_ul = NMPC_LD(w.ul, k * NU + j); n_pc = ivn[16 + j];
+            if (any_ipm) { n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; }
         };
         // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
         // which this sweep sees by itself; only a pass with pins (or a violation to correct) needs sweep C
@@ -478,7 +485,6 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             lt_solve(Lf, uh);
             {
-                const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
                 const T uj = sel4(uh, j);
                 if (cmpl && st_ok2) ivk[12 + j] = uj;
                 {
@@ -487,12 +493,15 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
                     dirty += clean ? T(0) : T(1);
                 }
-                const T d = uj - u;
-                const T dla = -ll - pr.kl * d, dua = -lu + pr.ku * d;
-                // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
-                const T a1 = d * pr.itl, a2 = d * pr.itu;
-                rmax = fmax(rmax, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
-                s2 += dla * d - dua * d;
+                if (any_ipm) {
+                    const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
+                    const T d = uj - u;
+                    const T dla = -ll - pr.kl * d, dua = -lu + pr.ku * d;
+                    // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
+                    const T a1 = d * pr.itl, a2 = d * pr.itu;
+                    rmax = fmax(rmax, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
+                    s2 += dla * d - dua * d;
+                }
             }
             if (pol2 && rowl && valid) tLM[k * TLM_ROWS + 66 + rr] = xh;   // xhat_k for the costate sweep
             {   // also through the last stage: the active-set check needs xhat_N
