@@ -161,6 +161,10 @@ const int32_t *nmpc_device_iterations(nmpc_solver *s);
 /* synchronises, then fills iteration / status histograms and kernel times of the last solve */
 int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out);
 
+/* on (default): every solve is bracketed by HIP events on its stream and nmpc_get_stats reports the
+ * kernel times; off: no events are recorded (two fewer stream operations per solve) and the times read 0 */
+int nmpc_set_timing(nmpc_solver *s, int on);
+
 /* message of the last failing call on this handle (s == NULL: of the last failed create) */
 const char *nmpc_last_error(const nmpc_solver *s);
 

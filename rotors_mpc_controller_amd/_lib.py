@@ -68,7 +68,7 @@ class NmpcStats(C.Structure):
 
 EXPORTS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
-    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_get_stats",
+    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_get_stats", "nmpc_set_timing",
     "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
 )
@@ -129,6 +129,8 @@ def load() -> C.CDLL:
     lib.nmpc_device_iterations.restype = vp
     lib.nmpc_get_stats.argtypes = [vp, C.POINTER(NmpcStats)]
     lib.nmpc_get_stats.restype = C.c_int
+    lib.nmpc_set_timing.argtypes = [vp, C.c_int]
+    lib.nmpc_set_timing.restype = C.c_int
     lib.nmpc_last_error.argtypes = [vp]
     lib.nmpc_last_error.restype = C.c_char_p
     lib.nmpc_build_hover_reference_device.argtypes = [vp, C.c_int, vp, vp, C.c_double, vp, vp, vp]

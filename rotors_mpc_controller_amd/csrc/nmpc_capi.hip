@@ -60,10 +60,16 @@ __global__ __launch_bounds__(64) void k_team_prepare(Consts<T> c, Work<T> w, Inp
 
 // QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
 // W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
+// fused != 0: the wave first prepares its own instances (same instance <-> team assignment), which saves
+// a launch and lets the solve start while other waves still linearise
 template <class T, int W, bool SHARED>
-__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Outputs<T> out, TeamWork<T> tw, int B)
+__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    if (fused) {
+        team_prepare(c, w, in, B);
+        __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
+    }
     team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw));
 }
 
@@ -85,11 +91,13 @@ struct nmpc_solver {
     uint64_t ws_bytes = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int last_B = 0;
-    bool timed = false;
+    bool timed = false, timed_fused = false, solved = false;
+    bool timing = true;   // nmpc_set_timing: HIP events around the kernels of every solve
     // single-instance slot (AcadosOcpSolver.set/get state)
     std::vector<double> sx, su, syref, syref_e, sx0;
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2|4 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
+    int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
 
     int fail(int code, const char *fmt, ...)
     {
@@ -236,6 +244,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         const int v = std::atoi(e);
         if (v == 1 || v == 2) s->team_occ = v;
     }
+    if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -280,7 +289,7 @@ const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : 
 
 template <class T>
 static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
-                  const void *x_init, const void *u_init, void *u0, void *x_out, void *u_out, hipStream_t st)
+                  const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
 {
     Consts<T> c;
     fill_consts(s->cfg, c);
@@ -298,20 +307,25 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
     in.yref_bcast = bcast;
     Outputs<T> out;
-    out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out;
+    out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out; out.status = status;
     const dim3 grid((B + 63) / 64), block(64);
-    HIP_TRY(s, hipEventRecord(s->ev[0], st));
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
     // team-mapped preparation below ~16k instances (few waves otherwise: 0.129 -> 0.041 ms at B = 4096);
     // above, one instance per lane already fills the chip and does no replicated work (B = 65536: 0.32 vs 0.52 ms)
     const bool team_only = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP) && B <= 16384;
     if (!((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP)))
         HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // only k_team_ipm writes it
-    if (team_only)
+    // fused: preparation inside k_team_ipm (NMPC_TEAM_FUSED=0 keeps the two-kernel form, e.g. for profiling)
+    const bool team_qp = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
+    const int fused = (team_qp && s->team_fused) ? 1 : 0;
+    if (fused)
+        ;
+    else if (team_only)
         hipLaunchKernelGGL(k_team_prepare<T>, dim3((B + 3) / 4), block, 0, st, c, w, in, B);
     else
         hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
     HIP_TRY(s, hipGetLastError());
-    HIP_TRY(s, hipEventRecord(s->ev[1], st));
+    if (s->timing && !fused) HIP_TRY(s, hipEventRecord(s->ev[1], st));
     if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
         CondWork<T> cw;
         const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
@@ -335,17 +349,19 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         // B = 65536: 13.9 M vs 8.3 M solves/s)
         if (occ == 0) occ = (sizeof(T) == 4 && B >= 16384) ? 2 : 1;
         const size_t lds = (size_t)tpw * TEAM_LDS * sizeof(T);
-        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, out, tw, B);
-        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, out, tw, B);
-        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, out, tw, B);
-        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, out, tw, B);
+        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
+        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
+        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
+        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }
     HIP_TRY(s, hipGetLastError());
-    HIP_TRY(s, hipEventRecord(s->ev[2], st));
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
     s->last_B = B;
-    s->timed = true;
+    s->solved = true;
+    s->timed = s->timing;
+    s->timed_fused = fused != 0;
     return 0;
 }
 
@@ -362,11 +378,9 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     hipStream_t st = (hipStream_t)hip_stream;
     int rc = s->cfg.dtype == NMPC_DTYPE_F64
-                 ? launch<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, x_out, u_out, st)
-                 : launch<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, x_out, u_out, st);
-    if (rc) return rc;
-    if (status) HIP_TRY(s, hipMemcpyAsync(status, s->d_status, (size_t)B * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
-    return 0;
+                 ? launch<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st)
+                 : launch<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
+    return rc;
 }
 
 static int ensure_staging(nmpc_solver *s, size_t B)
@@ -607,19 +621,32 @@ const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : 
 const long long *nmpc_debug_prof(nmpc_solver *s, int *stride) { if (stride) *stride = s->Bp; return s->d_prof; }
 #endif
 
+int nmpc_set_timing(nmpc_solver *s, int on)
+{
+    if (!s) return NMPC_EARG;
+    s->timing = on != 0;
+    return 0;
+}
+
 int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out)
 {
     if (!s || !out) return NMPC_EARG;
     std::memset(out, 0, sizeof(*out));
     out->workspace_bytes = s->ws_bytes;
-    if (!s->timed) return 0;
+    if (!s->solved) return 0;
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     HIP_TRY(s, hipDeviceSynchronize());
-    float a = 0, b = 0;
-    HIP_TRY(s, hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
-    HIP_TRY(s, hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
-    out->ms_prepare = a;
-    out->ms_solve = b;
+    if (s->timed) {
+        float a = 0, b = 0;
+        if (s->timed_fused) {        // one kernel: preparation and QP phase are not separable
+            HIP_TRY(s, hipEventElapsedTime(&b, s->ev[0], s->ev[2]));
+        } else {
+            HIP_TRY(s, hipEventElapsedTime(&a, s->ev[0], s->ev[1]));
+            HIP_TRY(s, hipEventElapsedTime(&b, s->ev[1], s->ev[2]));
+        }
+        out->ms_prepare = a;
+        out->ms_solve = b;
+    }
     const int B = s->last_B;
     std::vector<int32_t> it(B), st(B);
     HIP_TRY(s, hipMemcpy(it.data(), s->d_iters, (size_t)B * 4, hipMemcpyDeviceToHost));

@@ -457,6 +457,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     w.iters[lane] = it;
     w.status[lane] = nlp_status;
+    if (out.status) out.status[lane] = nlp_status;
     for (int i = 0; i < NU; i++) out.u0[(size_t)lane * NU + i] = nlp_status == 0 ? NMPC_LD(w.ul, i) : T(0);
     if (out.x_out)
         for (int k = 0; k <= N; k++)

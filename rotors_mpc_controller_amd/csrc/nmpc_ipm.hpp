@@ -39,6 +39,7 @@ struct Outputs {
     T *u0;            // [B][4]
     T *x_out;         // [B][N+1][13] or null
     T *u_out;         // [B][N][4] or null
+    int32_t *status = nullptr;   // [B] caller's status array (device) or null; the workspace copy is always kept
 };
 
 template <class T>
@@ -308,6 +309,7 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     w.iters[lane] = it;
     w.status[lane] = nlp_status;
+    if (out.status) out.status[lane] = nlp_status;
     NMPC_UNROLL for (int i = 0; i < NU; i++)
         out.u0[(size_t)lane * NU + i] = nlp_status == 0 ? NMPC_LD(w.ul, i) : T(0);   // controller.py:448-452
     if (out.x_out) {

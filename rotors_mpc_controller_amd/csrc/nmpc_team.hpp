@@ -835,6 +835,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     NMPC_PROF_END(w)
     const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
     if (valid) {
+        if (r == 0 && out.status) out.status[inst] = nlp_status;
         if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; if (w.npol) w.npol[inst] = from_ua ? npol : -npol; }   // > 0: accepted active-set solution
         if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? u0_new : T(0);   // controller.py:448-452
         if (outputs_done) return;

@@ -148,6 +148,10 @@ class NmpcOcpSolver:
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 
+    def set_timing(self, on: bool) -> None:
+        """HIP events around the kernels of every solve (default on; stats() then reports kernel times)."""
+        self._check(self._lib.nmpc_set_timing(self._h, int(bool(on))))
+
     def stats(self) -> dict:
         st = NmpcStats()
         self._check(self._lib.nmpc_get_stats(self._h, C.byref(st)))

@@ -10,7 +10,7 @@ for args in "" "--no-share" "--dist aggressive" "--batch 65536" "--batch 65536 -
 import json, sys
 d = json.load(open("gpurun_out/bench_q.json"))
 r = d["roofline"]
-print(f"[{sys.argv[1]:32s}] {d['value']/1e6:8.3f} M/s  step {d['ms_per_step']:.4f} ms  kernel {r['kernel_ms']:.4f}  prep {r['prepare_ms']:.4f}  "
+print(f"[{sys.argv[1]:32s}] {d['value']/1e6:8.3f} M/s  step {d['ms_per_step']:.4f} ms  kernel {r['kernel_ms']:.4f} (isolated {r['kernel_ms_isolated']:.4f})  prep {r['prepare_ms']:.4f}  "
       f"ipm {d['ipm_iterations']['mean']:.2f}/{d['ipm_iterations']['max']}  pol {d['active_set_passes']['mean']:.3f}/{d['active_set_passes']['max']}  st {d['status_histogram']}")
 PY
 done
