@@ -896,39 +896,21 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     const T Wqr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Wq[i] : v; return v; }();
     const T WqNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.WqN[i] : v; return v; }();
     const T Wrj = sel4(c.Wr, j);
-    // staging and cost gradients (U4).  Loads are issued a chunk of stages at a time before any store:
-    // the workspace stores may alias the inputs as far as the compiler knows, and a load-store-load
-    // chain per stage costs one HBM round trip each (21 of them dominated this kernel).
+    // staging and cost gradients (U4).  The inputs of the first HC stages are fetched BEFORE the
+    // linearisation so that its arithmetic hides their latency; every later load is issued a chunk of
+    // stages at a time before any store (the workspace stores may alias the inputs as far as the
+    // compiler knows, and a load-store-load chain per stage costs one HBM round trip each).
     const T x0r = x0[rr];
-    constexpr int CH = 8;
-    for (int k0 = 0; k0 < N; k0 += CH) {
-        T xv[CH], uv[CH], yx[CH], yu[CH];
-        NMPC_UNROLL for (int i = 0; i < CH; i++) {
-            const int k = (k0 + i < N) ? k0 + i : N - 1;
-            xv[i] = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r;     // stage 0 is pinned to x0
-            uv[i] = warm ? ui[(size_t)k * NU + j] : T(0);
-            yx[i] = yr[(size_t)k * NY + rr];
-            yu[i] = yr[(size_t)k * NY + NX + j];
-        }
-        NMPC_UNROLL for (int i = 0; i < CH; i++) {
-            const int k = k0 + i;
-            if (k < N && valid) {
-                if (rowl) {
-                    NMPC_ST(w.xl, k * NX + rr, xv[i]);
-                    NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
-                }
-                if (cmpl) {
-                    NMPC_ST(w.ul, k * NU + j, uv[i]);
-                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
-                }
-            }
-        }
+    constexpr int HC = 20, CH = 8;
+    T hx[HC], hu[HC], hyx[HC], hyu[HC];
+    NMPC_UNROLL for (int i = 0; i < HC; i++) {
+        const int k = i < N ? i : N - 1;
+        hx[i] = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r;         // stage 0 is pinned to x0
+        hu[i] = warm ? ui[(size_t)k * NU + j] : T(0);
+        hyx[i] = yr[(size_t)k * NY + rr];
+        hyu[i] = yr[(size_t)k * NY + NX + j];
     }
-    if (rowl && valid) {
-        const T xN = warm ? xi[(size_t)N * NX + rr] : x0r;
-        NMPC_ST(w.xl, N * NX + rr, xN);
-        NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xN - ye[rr]));
-    }
+    const T xN = warm ? xi[(size_t)N * NX + rr] : x0r, yeN = ye[rr];
     // linearisation: one interval if the cold start lets all stages share it
     const int Ns = c.shared ? 1 : N;
     const int col = r < 11 ? r : 10;
@@ -967,6 +949,45 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
                 a[156 + rr] = xnr - xn1;
             }
         }
+    }
+    NMPC_UNROLL for (int i = 0; i < HC; i++) {
+        if (i < N && valid) {
+            if (rowl) {
+                NMPC_ST(w.xl, i * NX + rr, hx[i]);
+                NMPC_ST(w.qr, i * QR_ROWS + rr, Wqr * (hx[i] - hyx[i]));
+            }
+            if (cmpl) {
+                NMPC_ST(w.ul, i * NU + j, hu[i]);
+                NMPC_ST(w.qr, i * QR_ROWS + NX + j, Wrj * (hu[i] - hyu[i]));
+            }
+        }
+    }
+    for (int k0 = HC; k0 < N; k0 += CH) {
+        T xv[CH], uv[CH], yx[CH], yu[CH];
+        NMPC_UNROLL for (int i = 0; i < CH; i++) {
+            const int k = (k0 + i < N) ? k0 + i : N - 1;
+            xv[i] = warm ? xi[(size_t)k * NX + rr] : x0r;
+            uv[i] = warm ? ui[(size_t)k * NU + j] : T(0);
+            yx[i] = yr[(size_t)k * NY + rr];
+            yu[i] = yr[(size_t)k * NY + NX + j];
+        }
+        NMPC_UNROLL for (int i = 0; i < CH; i++) {
+            const int k = k0 + i;
+            if (k < N && valid) {
+                if (rowl) {
+                    NMPC_ST(w.xl, k * NX + rr, xv[i]);
+                    NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
+                }
+                if (cmpl) {
+                    NMPC_ST(w.ul, k * NU + j, uv[i]);
+                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
+                }
+            }
+        }
+    }
+    if (rowl && valid) {
+        NMPC_ST(w.xl, N * NX + rr, xN);
+        NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xN - yeN));
     }
 }
 
