@@ -66,11 +66,12 @@ template <class T, int W, bool SHARED>
 __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const long long t_entry = NMPC_PROF_NOW();
     if (fused) {
         team_prepare(c, w, in, B);
         __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
     }
-    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw));
+    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw), t_entry);
 }
 
 }  // namespace
@@ -310,9 +311,9 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out; out.status = status;
     const dim3 grid((B + 63) / 64), block(64);
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
-    // team-mapped preparation below ~16k instances (few waves otherwise: 0.129 -> 0.041 ms at B = 4096);
-    // above, one instance per lane already fills the chip and does no replicated work (B = 65536: 0.32 vs 0.52 ms)
-    const bool team_only = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP) && B <= 16384;
+    // the team kernels keep the stage vectors as [inst][rows], the lane kernels as [row][Bp]: a team-mapped
+    // QP phase is always paired with the team-mapped preparation
+    const bool team_only = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
     if (!((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP)))
         HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // only k_team_ipm writes it
     // fused: preparation inside k_team_ipm (NMPC_TEAM_FUSED=0 keeps the two-kernel form, e.g. for profiling)

@@ -86,7 +86,11 @@ struct Work {
 #define NMPC_PROF_BEGIN long long prof_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; long long prof_t_ = wall_clock64();
 #define NMPC_STAMP(i) { const long long t_ = wall_clock64(); prof_acc_[i] += t_ - prof_t_; prof_t_ = t_; }
 #define NMPC_PROF_END(w) if ((w).prof) { for (int i_ = 0; i_ < 8; i_++) (w).prof[(size_t)i_ * (w).Bp + lane] = prof_acc_[i_]; }
+#define NMPC_PROF_SINCE(t0) prof_acc_[7] = prof_t_ - (t0);   // slot 7: kernel entry -> first sweep (fused preparation, start point)
+#define NMPC_PROF_NOW() wall_clock64()
 #else
+#define NMPC_PROF_SINCE(t0)
+#define NMPC_PROF_NOW() 0ll
 #define NMPC_PROF_BEGIN
 #define NMPC_STAMP(i)
 #define NMPC_PROF_END(w)

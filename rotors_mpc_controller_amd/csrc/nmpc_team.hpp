@@ -79,6 +79,12 @@ struct TeamWork {
 #define NMPC_WSYNC() __syncthreads()
 #endif
 
+// Stage vectors of the team mapping are "array of structures": [inst][rows] with rows = (N+1)*13 (xl),
+// N*4 (ul), N*17+13 (qr) - a team touches contiguous 13- and 4-element runs (the lane kernels keep
+// the same buffers as [row][Bp], which is what coalesces for one instance per lane).
+#define NMPC_TLD(p, rows, row) ((p)[(size_t)inst * (size_t)(rows) + (size_t)(row)])
+#define NMPC_TST(p, rows, row, v) ((p)[(size_t)inst * (size_t)(rows) + (size_t)(row)] = (v))
+
 // hard fence for the machine scheduler: nothing is moved across it (used to keep LDS reads batched)
 #define NMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
 
@@ -133,7 +139,7 @@ struct Pair {
 // that the per-stage reload code and its address arithmetic do not exist in the shared variant
 template <class T, bool BATCH, bool SHARED>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
-                                         const TeamWork<T> &tw, int B, T *smem)
+                                         const TeamWork<T> &tw, int B, T *smem, long long t_entry = 0)
 {
     const int tid = threadIdx.x, team = tid >> 4, r = tid & 15;
     const int rr = r < NX ? r : NX - 1;   // row used for loads; rows 13..15 shadow row 12 and never store
@@ -142,7 +148,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     int inst = blockIdx.x * (blockDim.x >> 4) + team;   // 1, 2 or 4 teams per wave (launch decides)
     const bool valid = inst < B;
     if (!valid) inst = B - 1;             // idle teams shadow the last instance and never store
-    const int N = c.N, Bp = w.Bp, lane = inst;
+    const int N = c.N;
+    const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
+    const int lane = inst;   // index of the profiling slots (NMPC_PROFILE builds)
+    (void)lane;
     const T nc = T(2 * NU) * T(N);
     T *S = smem + team * TEAM_LDS;
     T *sAd = S + L_AD, *sB = S + L_B, *sbv = S + L_BV, *sPB = S + L_PB, *sh = S + L_H, *sPA = S + L_PA;
@@ -194,26 +203,35 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     if (SHARED) load_stage(0);
 
     const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
-    // ---- initial point
-    for (int k = 0; k < N; k++) {
-        const T ul = NMPC_LD(w.ul, k * NU + j);
-        const T lo = lbj - ul, hi = ubj - ul;
-        T thr = c.thr0;
-        if (c.thr0_rel * (hi - lo) > thr) thr = c.thr0_rel * (hi - lo);
-        if (hi - lo < T(2) * thr) thr = T(0.5) * (hi - lo);
-        T v = 0;
-        if (v - lo < thr) v = lo + thr;
-        if (hi - v < thr) v = hi - thr;
-        if (cmpl && valid) {
-            T *ivk = tIV + k * IV_ROWS;
-            ivk[j] = v;
-            ivk[4 + j] = c.mu0 / (v - lo);
-            ivk[8 + j] = c.mu0 / (hi - v);
-            ivk[16 + j] = 0;   // active-set guess: everything free
+    // ---- initial point (the linearisation inputs are fetched a chunk of stages at a time: the stores
+    // below may alias them as far as the compiler knows)
+    {
+        constexpr int CHI = 10;
+        for (int k0 = 0; k0 < N; k0 += CHI) {
+            T ulv[CHI];
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = NMPC_TLD(w.ul, ULR, ((k0 + i < N) ? k0 + i : N - 1) * NU + j);
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) {
+                const int k = k0 + i;
+                const T lo = lbj - ulv[i], hi = ubj - ulv[i];
+                T thr = c.thr0;
+                if (c.thr0_rel * (hi - lo) > thr) thr = c.thr0_rel * (hi - lo);
+                if (hi - lo < T(2) * thr) thr = T(0.5) * (hi - lo);
+                T v = 0;
+                if (v - lo < thr) v = lo + thr;
+                if (hi - v < thr) v = hi - thr;
+                if (k < N && cmpl && valid) {
+                    T *ivk = tIV + k * IV_ROWS;
+                    ivk[j] = v;
+                    ivk[4 + j] = c.mu0 / (v - lo);
+                    ivk[8 + j] = c.mu0 / (hi - v);
+                    ivk[16 + j] = 0;   // active-set guess: everything free
+                }
+            }
         }
     }
     __syncthreads();
     NMPC_PROF_BEGIN
+    NMPC_PROF_SINCE(t_entry)
     T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu;
     int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
     int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
@@ -253,7 +271,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         T Prow[NX], pv;
         if (ks == N - 1) {
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = (cc == rr) ? QdNr : T(0);
-            pv = NMPC_LD(w.qr, N * QR_ROWS + rr);
+            pv = NMPC_TLD(w.qr, QRR, N * QR_ROWS + rr);
         } else {                      // resume from the checkpoint an earlier active-set pass left
             const T *cp = tP + ((size_t)(ks + 1) * NX + rr) * TP_ROW;
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = cp[cc];
@@ -263,9 +281,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // a wave whose live teams are all in active-set passes skips the barrier terms (wave-uniform)
         const bool any_ipm = __ballot(ipm) != 0;
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        T n_ul = NMPC_LD(w.ul, ks * NU + j), n_u = 0, n_ll = 0, n_lu = 0,
+        T n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j), n_u = 0, n_ll = 0, n_lu = 0,
           n_pc = tIV[ks * IV_ROWS + 16 + j],
-          n_rk = NMPC_LD(w.qr, ks * QR_ROWS + NX + j), n_qr = NMPC_LD(w.qr, ks * QR_ROWS + rr);
+          n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
         if (any_ipm) { n_u = tIV[ks * IV_ROWS + j]; n_ll = tIV[ks * IV_ROWS + 4 + j]; n_lu = tIV[ks * IV_ROWS + 8 + j]; }
         for (int k = ks; k >= 0; k--) {
             if (!SHARED) load_stage(k);
@@ -273,9 +291,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
             if (k > 0) {
                 const T *ivn = tIV + (k - 1) * IV_ROWS;
-                n_ul = NMPC_LD(w.ul, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                n_ul = NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
                 if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
-                n_rk = NMPC_LD(w.qr, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_LD(w.qr, (k - 1) * QR_ROWS + rr);
+                n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
             }
             {   // IPM: barrier terms.  Active-set pass: no barrier, pinned inputs are taken out of B
                 // (free mask) and enter through b (pinned value); their own row keeps R_jj so u_j = bound.
@@ -461,7 +479,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) { nM[i] = lmn[rr * 4 + i]; nm[i] = lmn[62 + i]; }
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_LD(w.ul, k * NU + j); n_pc = ivn[16 + j];
+            n_ul = NMPC_TLD(w.ul, ULR, k * NU + j); n_pc = ivn[16 + j];
             if (any_ipm) { n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; }
         };
         // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
@@ -541,7 +559,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // ================= sweep C (teams in an active-set pass): costates by the adjoint recursion,
         // KKT check of the pinned solve, corrected active set (primal-dual active-set step)
         if (__ballot(need_c) != 0) {
-            T pi_r = QdNr * xh + NMPC_LD(w.qr, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
+            T pi_r = QdNr * xh + NMPC_TLD(w.qr, QRR, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
             int kchg = -1;           // highest stage whose pin set this check changes
             p = 0;
@@ -551,8 +569,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = (k0 - i > 0) ? k0 - i : 0;
                     const T *ivk = tIV + k * IV_ROWS;
-                    c_ul[i] = NMPC_LD(w.ul, k * NU + j); c_uj[i] = ivk[12 + j]; c_pc[i] = ivk[16 + j];
-                    c_rk[i] = NMPC_LD(w.qr, k * QR_ROWS + NX + j); c_qr[i] = NMPC_LD(w.qr, k * QR_ROWS + rr);
+                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = ivk[12 + j]; c_pc[i] = ivk[16 + j];
+                    c_rk[i] = NMPC_TLD(w.qr, QRR, k * QR_ROWS + NX + j); c_qr[i] = NMPC_TLD(w.qr, QRR, k * QR_ROWS + rr);
                     c_xk[i] = tLM[k * TLM_ROWS + 66 + rr];
                 }
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -619,7 +637,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) nM[i] = lmn[rr * 4 + i];
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_LD(w.ul, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_ua = ivn[12 + j];
+            n_ul = NMPC_TLD(w.ul, ULR, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_ua = ivn[12 + j];
         };
         prefetch_bwd(N - 1);
         for (int k = N - 1; k >= 0; k--) {
@@ -715,7 +733,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         T ms = 0;
         for (int k = 0; k < N; k++) {
             T *ivk = tIV + k * IV_ROWS;
-            const T ul = NMPC_LD(w.ul, k * NU + j);
+            const T ul = NMPC_TLD(w.ul, ULR, k * NU + j);
             T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
             const T lo = lbj - ul, hi = ubj - ul;
             const Pair<T> pr(u, ll, lu, lo, hi);
@@ -766,15 +784,15 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (fast) {
             // the workspace iterate (xl, ul) is not read again after this kernel: the new iterate goes
             // straight to the caller's arrays (13- and 4-element runs per team), or nowhere but u0
-            u0_new = NMPC_LD(w.ul, j) + tIV[uoff];
+            u0_new = NMPC_TLD(w.ul, ULR, j) + tIV[uoff];
             if (out.x_out || out.u_out) {
                 for (int k0 = 0; k0 <= N; k0 += CH) {
                     T uv[CH], ulv[CH], xlv[CH], xhv[CH];
                     NMPC_UNROLL for (int i = 0; i < CH; i++) {
                         const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
                         uv[i] = tIV[ku * IV_ROWS + uoff];
-                        ulv[i] = NMPC_LD(w.ul, ku * NU + j);
-                        xlv[i] = NMPC_LD(w.xl, k * NX + rr);
+                        ulv[i] = NMPC_TLD(w.ul, ULR, ku * NU + j);
+                        xlv[i] = NMPC_TLD(w.xl, XLR, k * NX + rr);
                         xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot
                     }
                     NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -794,8 +812,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
                 const int k = (k0 + i < N) ? k0 + i : N - 1;
                 uv[i] = tIV[k * IV_ROWS + uoff];
-                ulv[i] = NMPC_LD(w.ul, k * NU + j);
-                xlv[i] = NMPC_LD(w.xl, (k + 1) * NX + rr);
+                ulv[i] = NMPC_TLD(w.ul, ULR, k * NU + j);
+                xlv[i] = NMPC_TLD(w.xl, XLR, (k + 1) * NX + rr);
             }
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
                 const int k = k0 + i;
@@ -813,8 +831,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     NMPC_UNROLL for (int ii = 0; ii < NU; ii++) a += Brow[ii] * du[ii];
                     dx = a;
                     if (upd && valid) {
-                        if (cmpl) NMPC_ST(w.ul, k * NU + j, ulv[i] + u);
-                        if (rowl) NMPC_ST(w.xl, (k + 1) * NX + rr, xlv[i] + dx);
+                        if (cmpl) NMPC_TST(w.ul, ULR, k * NU + j, ulv[i] + u);
+                        if (rowl) NMPC_TST(w.xl, XLR, (k + 1) * NX + rr, xlv[i] + dx);
                     }
                     p ^= 1;
                 }
@@ -828,7 +846,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             T nb = 0;
             NMPC_UNROLL for (int l = 0; l < NX; l++) nb += sXh[l];
             if (nb > T(0) && upd) status = 1;
-            u0_new = NMPC_LD(w.ul, j);
+            u0_new = NMPC_TLD(w.ul, ULR, j);
         }
     }
     NMPC_STAMP(6)
@@ -840,10 +858,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? u0_new : T(0);   // controller.py:448-452
         if (outputs_done) return;
         if (out.x_out && rowl) {
-            for (int k = 0; k <= N; k++) out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = NMPC_LD(w.xl, k * NX + rr);
+            for (int k = 0; k <= N; k++) out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = NMPC_TLD(w.xl, XLR, k * NX + rr);
         }
         if (out.u_out && cmpl) {
-            for (int k = 0; k < N; k++) out.u_out[((size_t)inst * N + k) * NU + j] = NMPC_LD(w.ul, k * NU + j);
+            for (int k = 0; k < N; k++) out.u_out[((size_t)inst * N + k) * NU + j] = NMPC_TLD(w.ul, ULR, k * NU + j);
         }
     }
 }
@@ -886,7 +904,8 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     int inst = blockIdx.x * (blockDim.x >> 4) + team;
     const bool valid = inst < B;
     if (!valid) inst = B - 1;
-    const int N = c.N, Bp = w.Bp, lane = inst;
+    const int N = c.N;
+    const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
     const bool warm = in.x_init != nullptr && in.u_init != nullptr;
     const T *x0 = in.x0 + (size_t)inst * NX;
     const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
@@ -953,12 +972,12 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     NMPC_UNROLL for (int i = 0; i < HC; i++) {
         if (i < N && valid) {
             if (rowl) {
-                NMPC_ST(w.xl, i * NX + rr, hx[i]);
-                NMPC_ST(w.qr, i * QR_ROWS + rr, Wqr * (hx[i] - hyx[i]));
+                NMPC_TST(w.xl, XLR, i * NX + rr, hx[i]);
+                NMPC_TST(w.qr, QRR, i * QR_ROWS + rr, Wqr * (hx[i] - hyx[i]));
             }
             if (cmpl) {
-                NMPC_ST(w.ul, i * NU + j, hu[i]);
-                NMPC_ST(w.qr, i * QR_ROWS + NX + j, Wrj * (hu[i] - hyu[i]));
+                NMPC_TST(w.ul, ULR, i * NU + j, hu[i]);
+                NMPC_TST(w.qr, QRR, i * QR_ROWS + NX + j, Wrj * (hu[i] - hyu[i]));
             }
         }
     }
@@ -975,19 +994,19 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
             const int k = k0 + i;
             if (k < N && valid) {
                 if (rowl) {
-                    NMPC_ST(w.xl, k * NX + rr, xv[i]);
-                    NMPC_ST(w.qr, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
+                    NMPC_TST(w.xl, XLR, k * NX + rr, xv[i]);
+                    NMPC_TST(w.qr, QRR, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
                 }
                 if (cmpl) {
-                    NMPC_ST(w.ul, k * NU + j, uv[i]);
-                    NMPC_ST(w.qr, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
+                    NMPC_TST(w.ul, ULR, k * NU + j, uv[i]);
+                    NMPC_TST(w.qr, QRR, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
                 }
             }
         }
     }
     if (rowl && valid) {
-        NMPC_ST(w.xl, N * NX + rr, xN);
-        NMPC_ST(w.qr, N * QR_ROWS + rr, WqNr * (xN - yeN));
+        NMPC_TST(w.xl, XLR, N * NX + rr, xN);
+        NMPC_TST(w.qr, QRR, N * QR_ROWS + rr, WqNr * (xN - yeN));
     }
 }
 

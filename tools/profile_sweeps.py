@@ -53,7 +53,7 @@ hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
 assert hip.hipMemcpy(host.ctypes.data, dptr, host.nbytes, 2) == 0
 grp = 64 if a.mapping == 'lane' else 4
 per_wave = host[:, :B].reshape(8, -1, grp)[:, :, 0] * 0.01   # s_memrealtime ticks at 100 MHz -> us
-names = ["A factor(bwd)", "B fwd affine", "D bwd homog", "E fwd homog", "F mu sweep", "(loop exit)", "final rollout"]
+names = ["A factor(bwd)", "B fwd affine", "D bwd homog", "E fwd homog", "F mu sweep", "C check + exit", "final sweep", "prepare + start point"]
 tot = per_wave.sum(0)
 print(f"batch {B} dtype {a.dtype} share={not a.no_share}: kernel {st['ms_solve']:.3f} ms, prepare {st['ms_prepare']:.3f} ms, "
       f"iters mean {st['iter_mean']:.2f} max {st['iter_max']}")
