@@ -203,9 +203,14 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     if (SHARED) load_stage(0);
 
     const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
-    // ---- initial point (the linearisation inputs are fetched a chunk of stages at a time: the stores
-    // below may alias them as far as the compiler knows)
-    {
+    // ---- active-set guess of the first pass: everything free.  The interior point iterate itself is
+    // only written when a team first enters that mode (init_point below): with the polish on, most
+    // instances never do.
+    if (cmpl && valid) {
+        for (int k = 0; k < N; k++) tIV[k * IV_ROWS + 16 + j] = 0;
+    }
+    // the linearisation inputs are fetched a chunk of stages at a time: the stores may alias them
+    auto init_point = [&](bool mine) {
         constexpr int CHI = 10;
         for (int k0 = 0; k0 < N; k0 += CHI) {
             T ulv[CHI];
@@ -219,16 +224,16 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T v = 0;
                 if (v - lo < thr) v = lo + thr;
                 if (hi - v < thr) v = hi - thr;
-                if (k < N && cmpl && valid) {
+                if (k < N && cmpl && valid && mine) {
                     T *ivk = tIV + k * IV_ROWS;
                     ivk[j] = v;
                     ivk[4 + j] = c.mu0 / (v - lo);
                     ivk[8 + j] = c.mu0 / (hi - v);
-                    ivk[16 + j] = 0;   // active-set guess: everything free
                 }
             }
         }
-    }
+    };
+    bool have_point = false;
     __syncthreads();
     NMPC_PROF_BEGIN
     NMPC_PROF_SINCE(t_entry)
@@ -255,6 +260,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         const bool act = mode != M_DONE;  // frozen teams keep computing but never store
         const bool st_ok = act && valid;
         if (ipm) it++;
+        if (__ballot(ipm && !have_point) != 0) {      // first interior point iteration of some team
+            init_point(ipm && !have_point);
+            __syncthreads();
+        }
+        have_point |= ipm;
         // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
         int ks = N - 1;
         if (tP) {
