@@ -620,6 +620,16 @@ const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : 
 #ifdef NMPC_PROFILE
 // diagnostic builds only (tools/profile_sweeps.py): int64 [8][Bp] DEVICE pointer and its row stride
 const long long *nmpc_debug_prof(nmpc_solver *s, int *stride) { if (stride) *stride = s->Bp; return s->d_prof; }
+// copies the [8][Bp] stamp table to the host through THIS library's HIP runtime (a second runtime loaded
+// by the caller must not touch the pointer); returns the row stride Bp, or a negative error code
+int nmpc_debug_prof_copy(nmpc_solver *s, long long *host)
+{
+    if (!s || !host || !s->d_prof) return NMPC_EARG;
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    HIP_TRY(s, hipDeviceSynchronize());
+    HIP_TRY(s, hipMemcpy(host, s->d_prof, (size_t)8 * s->Bp * sizeof(long long), hipMemcpyDeviceToHost));
+    return s->Bp;
+}
 #endif
 
 int nmpc_set_timing(nmpc_solver *s, int on)

@@ -42,15 +42,11 @@ for _ in range(3):
     out = s.solve_batch(x0, yref, ye)
 st = s.stats()
 lib = _lib.load()
-lib.nmpc_debug_prof.argtypes = [C.c_void_p, C.POINTER(C.c_int)]
-lib.nmpc_debug_prof.restype = C.c_void_p
-stride = C.c_int(0)
-dptr = lib.nmpc_debug_prof(s._h, C.byref(stride))
-Bp = stride.value
+lib.nmpc_debug_prof_copy.argtypes = [C.c_void_p, C.c_void_p]
+lib.nmpc_debug_prof_copy.restype = C.c_int
+Bp = (B + 63) // 64 * 64
 host = np.zeros((8, Bp), dtype=np.int64)
-hip = C.CDLL("libamdhip64.so")
-hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-assert hip.hipMemcpy(host.ctypes.data, dptr, host.nbytes, 2) == 0
+assert lib.nmpc_debug_prof_copy(s._h, host.ctypes.data) == Bp
 grp = 64 if a.mapping == 'lane' else 4
 per_wave = host[:, :B].reshape(8, -1, grp)[:, :, 0] * 0.01   # s_memrealtime ticks at 100 MHz -> us
 names = ["A factor(bwd)", "B fwd affine", "D bwd homog", "E fwd homog", "F mu sweep", "C check + exit", "final sweep", "prepare + start point"]
