@@ -55,7 +55,7 @@ __global__ __launch_bounds__(64) void k_cond_ipm(Consts<T> c, Work<T> w, CondWor
 template <class T>
 __global__ __launch_bounds__(64) void k_team_prepare(Consts<T> c, Work<T> w, Inputs<T> in, int B)
 {
-    team_prepare(c, w, in, B);
+    team_prepare(c, w, in, B, 4);
 }
 
 // QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
@@ -63,15 +63,15 @@ __global__ __launch_bounds__(64) void k_team_prepare(Consts<T> c, Work<T> w, Inp
 // fused != 0: the wave first prepares its own instances (same instance <-> team assignment), which saves
 // a launch and lets the solve start while other waves still linearise
 template <class T, int W, bool SHARED>
-__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused)
+__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused, int tpw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long long t_entry = NMPC_PROF_NOW();
     if (fused) {
-        team_prepare(c, w, in, B);
+        team_prepare(c, w, in, B, tpw);
         __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
     }
-    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, reinterpret_cast<T *>(smem_raw), t_entry);
+    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry);
 }
 
 }  // namespace
@@ -343,17 +343,17 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         // put two waves on every SIMD, so that LDS/memory latency still has something to hide behind
         int tpw = s->team_tpw;
         if (tpw == 0) tpw = (B >= 2048) ? 4 : (B >= 512 ? 2 : 1);   // measured: 4 is best from B = 4096 up
-        const dim3 tgrid((B + tpw - 1) / tpw), tblock(16 * tpw);
+        const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);   // always a full wave: idle teams shadow
         int occ = s->team_occ;
         // register budget: FP64 needs the whole 512-register file (the 256-register build spills);
         // FP32 fits 256 and gains from two waves per SIMD once the batch supplies them (measured at
         // B = 65536: 13.9 M vs 8.3 M solves/s)
         if (occ == 0) occ = (sizeof(T) == 4 && B >= 16384) ? 2 : 1;
-        const size_t lds = (size_t)tpw * TEAM_LDS * sizeof(T);
-        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
-        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
-        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
-        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused);
+        const size_t lds = (size_t)4 * TEAM_LDS * sizeof(T);
+        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
+        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
+        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
+        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }

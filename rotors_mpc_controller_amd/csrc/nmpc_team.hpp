@@ -52,11 +52,13 @@ constexpr int L_XH = L_Y + 128;     // [2][16]
 constexpr int L_DR = L_XH + 32;     // [2][4]
 constexpr int L_RED = L_DR + 8;     // [32] small reductions
 constexpr int L_Z = L_RED + 32;     // [32] the 28 entries of the (q,omega)x(q,omega) block of A'PA
-// 848 elements: as bytes (6784 B FP64 / 3392 B FP32) the team stride is 128 B resp. 64 B past a
-// multiple of the 256-B LDS bank row, so the four teams of a wave - which issue the same relative
-// address at the same time - fall on different banks.  (A stride of 800 doubles = 25 bank rows
-// made every broadcast read a 4-way conflict: SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles.)
-constexpr int TEAM_LDS = L_Z + 40;
+// 856 elements: as bytes (6848 B FP64 / 3424 B FP32) the team stride is 192 B resp. 96 B past a
+// multiple of the 256-B LDS bank row, so the four teams of a wave - whose lanes are interleaved in
+// every 16-lane service group and issue the same relative address at the same time - start 0, 192,
+// 128, 64 B (FP32: 0, 96, 192, 32 B) into a bank row and never share a bank on a 16-byte access.
+// (A stride of 800 doubles = 25 bank rows made every broadcast read a 4-way conflict:
+// SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles; 848 = 128 B past a row is 2-way with this lane map.)
+constexpr int TEAM_LDS = L_Z + 48;
 
 template <class T>
 struct TeamWork {
@@ -139,14 +141,17 @@ struct Pair {
 // that the per-stage reload code and its address arithmetic do not exist in the shared variant
 template <class T, bool BATCH, bool SHARED>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
-                                         const TeamWork<T> &tw, int B, T *smem, long long t_entry = 0)
+                                         const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0)
 {
-    const int tid = threadIdx.x, team = tid >> 4, r = tid & 15;
+    // lane -> (team, row): team b owns lanes {16a + 4b + c}, row r = 4a + c.  This is the block layout of
+    // v_mfma_f64_4x4x4_4b_f64 (operand/result element (a,c) of block b sits in lane 16a + 4b + c, probed
+    // with tools/probe_mfma), so a 4x4 tile of a team's matrices is one register across the team.
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
     const int rr = r < NX ? r : NX - 1;   // row used for loads; rows 13..15 shadow row 12 and never store
     const int j = r & 3;                  // input component handled by lanes r < 4 (others shadow)
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * (blockDim.x >> 4) + team;   // 1, 2 or 4 teams per wave (launch decides)
-    const bool valid = inst < B;
+    int inst = blockIdx.x * tpw + team;   // 1, 2 or 4 live teams per wave (launch decides)
+    const bool valid = team < tpw && inst < B;
     if (!valid) inst = B - 1;             // idle teams shadow the last instance and never store
     const int N = c.N;
     const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
@@ -160,7 +165,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     T *tLM = tw.tLM + (size_t)inst * N * TLM_ROWS, *tIV = tw.tIV + (size_t)inst * N * IV_ROWS;
     const int ckpt = c.polish_ckpt;       // checkpoints exist for stages 1..ckpt
     T *tP = tw.tP ? tw.tP + (size_t)inst * (ckpt + 1) * TP_ROWS : nullptr;
-    const int nteams = blockDim.x >> 4;
+    const int nteams = 4;
 
     // the two (a,b) entries of the packed 7x7 block this lane computes in the P update
     int za0 = 0, zb0 = 0, za1 = 0, zb1 = 0;
@@ -242,7 +247,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
     // per-team mode: interior point iteration, active-set (polish) pass, or finished
     enum { M_IPM = 0, M_POL = 1, M_DONE = 2 };
-    int mode = M_IPM;
+    int mode = valid ? M_IPM : M_DONE;      // idle teams never hold the wave back
     bool from_ua = false;   // the accepted active-set solution lives in the u_aff slot
     const T Qdr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Qd[i] : v; return v; }();
     const T QdNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.QdN[i] : v; return v; }();
@@ -906,13 +911,13 @@ __device__ __forceinline__ void vde_col_rt(const Consts<T> &c, const Jac<T> &J, 
 }
 
 template <class T>
-__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B)
+__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B, int tpw)
 {
-    const int tid = threadIdx.x, team = tid >> 4, r = tid & 15;
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
     const int rr = r < NX ? r : NX - 1, j = r & 3;
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * (blockDim.x >> 4) + team;
-    const bool valid = inst < B;
+    int inst = blockIdx.x * tpw + team;
+    const bool valid = team < tpw && inst < B;
     if (!valid) inst = B - 1;
     const int N = c.N;
     const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
