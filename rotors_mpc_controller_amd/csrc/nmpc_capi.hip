@@ -62,7 +62,8 @@ __global__ __launch_bounds__(64) void k_team_prepare(Consts<T> c, Work<T> w, Inp
 // W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
 // fused != 0: the wave first prepares its own instances (same instance <-> team assignment), which saves
 // a launch and lets the solve start while other waves still linearise
-template <class T, int W, bool SHARED>
+// MF: tile form of the factor sweep on v_mfma_f64_4x4x4 (FP64 only)
+template <class T, int W, bool SHARED, bool MF>
 __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused, int tpw)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
         team_prepare(c, w, in, B, tpw);
         __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
     }
-    team_ipm<T, W == 1, SHARED>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry);
+    team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry);
 }
 
 }  // namespace
@@ -99,6 +100,7 @@ struct nmpc_solver {
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2|4 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
+    int team_mfma = 1;  // FP64 factor sweep in tile form on v_mfma_f64_4x4x4; NMPC_TEAM_MFMA=0 keeps the VALU form
 
     int fail(int code, const char *fmt, ...)
     {
@@ -246,6 +248,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         if (v == 1 || v == 2) s->team_occ = v;
     }
     if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -350,10 +353,21 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         // B = 65536: 13.9 M vs 8.3 M solves/s)
         if (occ == 0) occ = (sizeof(T) == 4 && B >= 16384) ? 2 : 1;
         const size_t lds = (size_t)4 * TEAM_LDS * sizeof(T);
-        if (occ == 1 && c.shared) hipLaunchKernelGGL((k_team_ipm<T, 1, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
-        else if (occ == 1) hipLaunchKernelGGL((k_team_ipm<T, 1, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
-        else if (c.shared) hipLaunchKernelGGL((k_team_ipm<T, 2, true>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
-        else hipLaunchKernelGGL((k_team_ipm<T, 2, false>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw);
+        constexpr bool F64 = sizeof(T) == 8;
+        const bool mf = F64 && s->team_mfma;
+#define NMPC_LAUNCH_TEAM(W_, SH_, MF_) hipLaunchKernelGGL((k_team_ipm<T, W_, SH_, MF_>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw)
+        if (mf) {
+            if (occ == 1 && c.shared) NMPC_LAUNCH_TEAM(1, true, F64);
+            else if (occ == 1) NMPC_LAUNCH_TEAM(1, false, F64);
+            else if (c.shared) NMPC_LAUNCH_TEAM(2, true, F64);
+            else NMPC_LAUNCH_TEAM(2, false, F64);
+        } else {
+            if (occ == 1 && c.shared) NMPC_LAUNCH_TEAM(1, true, false);
+            else if (occ == 1) NMPC_LAUNCH_TEAM(1, false, false);
+            else if (c.shared) NMPC_LAUNCH_TEAM(2, true, false);
+            else NMPC_LAUNCH_TEAM(2, false, false);
+        }
+#undef NMPC_LAUNCH_TEAM
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }

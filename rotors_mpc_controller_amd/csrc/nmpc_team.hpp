@@ -36,7 +36,7 @@ constexpr int TEAMS_PER_WAVE = 4;
 constexpr int TLM_ROWS = 80;       // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad
 constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
 constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
-constexpr int TP_ROWS = NX * TP_ROW;
+constexpr int TP_ROWS = 256;        // per stage: 13 x 14 (VALU form) or 16 tiles x 16 lanes (MFMA form)
 // LDS carve per team, in elements of T
 constexpr int L_AD = 0;             // [16][8]   rows of the dense A columns
 constexpr int L_B = L_AD + 128;     // [16][4]
@@ -115,6 +115,36 @@ __device__ __forceinline__ float fast_rsqrt(float x)
     return __builtin_fmaf(0.5f * y, __builtin_fmaf(-x * y, y, 1.0f), y);
 }
 
+// D = A^T * B + C on 4x4 tiles of four independent blocks (= the four teams of a wave): element (a,c) of
+// every operand and of the result sits in lane 16a + 4b + c of block b, so the A operand is read as the
+// TRANSPOSE of the tile stored that way (layout and rate probed with tools/probe_mfma: one wave alone
+// reaches the full FP64 rate with this instruction, but only half of it with v_fma_f64).
+__device__ __forceinline__ double mfma44(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float mfma44(float, float, float c) { return c; }   // FP32 keeps the VALU form
+
+// padded state order of the tile form: p(3) _ | v(3) _ | q(4) | omega(3) 1   (index 15 is the homogeneous
+// coordinate that carries b, p and the gradients); natural index of element e of tile t, -1 for a pad
+__device__ __forceinline__ constexpr int nat_of(int t, int e)
+{
+    return t == 0 ? (e < 3 ? e : -1) : (t == 1 ? (e < 3 ? 3 + e : -1) : (t == 2 ? 6 + e : (e < 3 ? 10 + e : -1)));
+}
+
+template <class T>
+__device__ __forceinline__ T pick13(const T *v, int i)
+{
+    T x = 0;
+    NMPC_UNROLL for (int l = 0; l < NX; l++) x = (l == i) ? v[l] : x;
+    return x;
+}
+
+template <class T>
+__device__ __forceinline__ T quad_sum(T x)     // over the 4 lanes 4q..4q+3 (the columns of one tile row)
+{
+    x += __shfl_xor(x, 1);
+    x += __shfl_xor(x, 2);
+    return x;
+}
+
 template <class T>
 __device__ __forceinline__ T sel4(const T *v, int j)
 {
@@ -139,7 +169,7 @@ struct Pair {
 // BATCH: read the LDS operands of the P*[B b A] products in fenced batches (1 wave per SIMD only)
 // SHARED: all stages use one (Ad, B, b) (cold start, NMPC_FLAG_SHARE_COLD_START) - compile time so
 // that the per-stage reload code and its address arithmetic do not exist in the shared variant
-template <class T, bool BATCH, bool SHARED>
+template <class T, bool BATCH, bool SHARED, bool MF>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
                                          const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0)
 {
@@ -283,7 +313,12 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         }
 
         // ================= sweep A: backward factorisation, affine right-hand side
-        T Prow[NX], pv;
+        bool ok = true, nanp = false;
+        // a wave whose live teams are all in active-set passes skips the barrier terms (wave-uniform)
+        const bool any_ipm = __ballot(ipm) != 0;
+        T pv = 0, n_ul = 0, n_pc = 0;       // also scratch of the later sweeps
+        if constexpr (!MF) {
+        T Prow[NX];
         if (ks == N - 1) {
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = (cc == rr) ? QdNr : T(0);
             pv = NMPC_TLD(w.qr, QRR, N * QR_ROWS + rr);
@@ -292,12 +327,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Prow[cc] = cp[cc];
             pv = cp[NX];
         }
-        bool ok = true, nanp = false;
-        // a wave whose live teams are all in active-set passes skips the barrier terms (wave-uniform)
-        const bool any_ipm = __ballot(ipm) != 0;
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        T n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j), n_u = 0, n_ll = 0, n_lu = 0,
-          n_pc = tIV[ks * IV_ROWS + 16 + j],
+        n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j);
+        n_pc = tIV[ks * IV_ROWS + 16 + j];
+        T n_u = 0, n_ll = 0, n_lu = 0,
           n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
         if (any_ipm) { n_u = tIV[ks * IV_ROWS + j]; n_ll = tIV[ks * IV_ROWS + 4 + j]; n_lu = tIV[ks * IV_ROWS + 8 + j]; }
         for (int k = ks; k >= 0; k--) {
@@ -474,6 +507,192 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
             }
             NMPC_WSYNC();
+        }
+        } else {
+            // ---- tile form (FP64): the stage is ~120 v_mfma_f64_4x4x4 on register tiles and one LDS
+            // exchange.  Pbar is the 16x16 matrix [[P p],[p' *]] in the padded order; Abar = [[A b],[0 1]]
+            // has dense columns only in the q / omega tiles (Aq0, Aq1; b sits in the pad column of Aq1),
+            // so P*A, A'(PA), B'PA, B'PB, the gradients and p_k all come out of the same tile products.
+            const int ta = r >> 2, tc = r & 3;
+            int natR[4], natC[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) { natR[t] = nat_of(t, ta); natC[t] = nat_of(t, tc); }
+            T Qdg[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) Qdg[t] = (ta == tc && natR[t] >= 0) ? pick13(c.Qd, natR[t]) : T(0);
+            T Aq0[4], Aq1b[4], Bt[4];
+            auto load_tiles = [&]() {
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    const int l = natR[kt] >= 0 ? natR[kt] : 0;
+                    const bool real = natR[kt] >= 0;
+                    const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc], bv_ = sbv[l];
+                    Aq0[kt] = real ? a0 : T(0);
+                    Aq1b[kt] = real ? (tc < 3 ? a1 : bv_) : ((kt == 3 && ta == 3 && tc == 3) ? T(1) : T(0));
+                    Bt[kt] = real ? bb : T(0);
+                }
+            };
+            if (SHARED) load_tiles();
+            T Pt[4][4];
+            if (ks == N - 1) {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                        T v = 0;
+                        if (it == jt && ta == tc && natR[it] >= 0) v = pick13(c.QdN, natR[it]);
+                        if (jt == 3 && tc == 3 && natR[it] >= 0) v = NMPC_TLD(w.qr, QRR, N * QR_ROWS + natR[it]);
+                        if (it == 3 && ta == 3 && natC[jt] >= 0) v = NMPC_TLD(w.qr, QRR, N * QR_ROWS + natC[jt]);
+                        Pt[it][jt] = v;
+                    }
+                }
+            } else {                  // resume from the checkpoint an earlier active-set pass left
+                const T *cp = tP + (size_t)(ks + 1) * TP_ROWS + r;
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
+                }
+            }
+            n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j);
+            n_pc = tIV[ks * IV_ROWS + 16 + j];
+            T n_u = 0, n_ll = 0, n_lu = 0,
+              n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
+            if (any_ipm) { n_u = tIV[ks * IV_ROWS + j]; n_ll = tIV[ks * IV_ROWS + 4 + j]; n_lu = tIV[ks * IV_ROWS + 8 + j]; }
+            for (int k = ks; k >= 0; k--) {
+                if (!SHARED) { load_stage(k); load_tiles(); }
+                T *lmk = tLM + k * TLM_ROWS;
+                const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
+                if (k > 0) {
+                    const T *ivn = tIV + (k - 1) * IV_ROWS;
+                    n_ul = NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                    if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
+                    n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
+                }
+                bool pinned;
+                {
+                    const T lo = lbj - ul, hi = ubj - ul;
+                    T sg = 0;
+                    if (any_ipm) {
+                        const Pair<T> pr(u, ll, lu, lo, hi);
+                        sg = pol ? T(0) : pr.kl + pr.ku;
+                    }
+                    pinned = pol && pc != T(0);
+                    const T vpin = pc < T(0) ? lo : hi;
+                    if (cmpl) {
+                        sD[j] = Rdj + sg;
+                        sD[4 + j] = pinned ? -Rdj * vpin : (pol ? rk : rk - sg * u);
+                        sD[8 + j] = pinned ? T(0) : T(1);
+                        sD[12 + j] = pinned ? vpin : T(0);
+                    }
+                    sh[r] = q_r;                     // natural row rr of the stage gradient
+                }
+                NMPC_WSYNC();
+                const T mask_a = sD[8 + ta], mask_c = sD[8 + tc], D_a = sD[ta], rhat_a = sD[4 + ta];
+                T Aq1[4];
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
+                if (__ballot(pinned) != 0) {         // pinned inputs enter through b (column 15 of Abar)
+                    const T vp = sD[12 + tc];
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                        const T sm = quad_sum(Bt[kt] * vp);
+                        if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
+                    }
+                }
+                // W = Pbar * [Aq0 | Aq1 | B]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt))
+                T W0[4], W1[4], WB[4];
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    T a0 = 0, a1 = 0, aB = 0;
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                        a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                        a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
+                        aB = mfma44(Pt[kt][it], Bt[kt], aB);
+                    }
+                    W0[it] = a0; W1[it] = a1; WB[it] = aB;
+                }
+                // column tiles of Pbar*Abar: the p and v columns of Abar are e_p and dt*e_p + e_v
+                T PA[4][4];
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    PA[kt][0] = Pt[kt][0];
+                    PA[kt][1] = c.dt * Pt[kt][0] + Pt[kt][1];
+                    PA[kt][2] = W0[kt];
+                    PA[kt][3] = W1[kt];
+                }
+                // X = B'(Pbar Abar) (column 15: B'h), Hr = B'PB
+                T X[4], Hr = 0;
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    T a = 0;
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a);
+                    X[jt] = mask_a * a;
+                }
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
+                if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
+                const T Huu = ((ta == tc) ? D_a : T(0)) + mask_a * mask_c * Hr;
+                if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
+                if (tc == 3) sHg[10 + ta] = X[3];
+                NMPC_WSYNC();
+                // Cholesky (replicated), m = L^-1 gu
+                T Lf[10], mv[NU];
+                NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
+                NMPC_UNROLL for (int i = 0; i < NU; i++) mv[i] = sHg[10 + i];
+                NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
+                    T d = Lf[lidx(jj, jj)];
+                    NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
+                    const bool pos = d > T(0);
+                    ok &= pos; nanp |= !(d == d); d = pos ? d : T(1);
+                    const T rd = fast_rsqrt(d);
+                    Lf[lidx(jj, jj)] = rd;
+                    NMPC_UNROLL for (int i = jj + 1; i < NU; i++) {
+                        T a = Lf[lidx(i, jj)];
+                        NMPC_UNROLL for (int l = 0; l < jj; l++) a -= Lf[lidx(i, l)] * Lf[lidx(jj, l)];
+                        Lf[lidx(i, jj)] = a * rd;
+                    }
+                }
+                l_solve(Lf, mv);
+                if (r == 0 && st_ok) {
+                    NMPC_UNROLL for (int i = 0; i < 10; i++) lmk[52 + i] = Lf[i];
+                    NMPC_UNROLL for (int i = 0; i < NU; i++) lmk[62 + i] = mv[i];
+                }
+                // Y = L^-T as a tile (lane (a,c) holds (L^-1 e_a)_c), M = L^-1 X = Y' X
+                T ea[NU];
+                NMPC_UNROLL for (int i = 0; i < NU; i++) ea[i] = (i == ta) ? T(1) : T(0);
+                l_solve(Lf, ea);
+                const T Y = sel4(ea, tc);
+                T M[4];
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    M[jt] = mfma44(Y, X[jt], T(0));
+                    if (st_ok && natC[jt] >= 0) lmk[natC[jt] * 4 + ta] = M[jt];
+                }
+                if (k > 0) {
+                    // rows of Abar'(Pbar Abar): p rows copy, v rows add dt * p rows, q / omega rows are products
+                    T qcol[4], qrow[4];
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+                        qcol[t] = (tc == 3 && natR[t] >= 0) ? sh[natR[t] >= 0 ? natR[t] : 0] : T(0);
+                        qrow[t] = (ta == 3 && natC[t] >= 0) ? sh[natC[t] >= 0 ? natC[t] : 0] : T(0);
+                    }
+                    T Pn[4][4];
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                        T a2 = 0, a3 = 0;
+                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                            a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                            a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                        }
+                        Pn[0][jt] = PA[0][jt];
+                        Pn[1][jt] = c.dt * PA[0][jt] + PA[1][jt];
+                        Pn[2][jt] = a2;
+                        Pn[3][jt] = a3;
+                    }
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                            T v = Pn[it][jt] - mfma44(M[it], M[jt], T(0));
+                            if (it == jt) v += Qdg[it];
+                            if (jt == 3) v += qcol[it];
+                            if (it == 3) v += qrow[jt];
+                            if (it == 3 && jt == 3 && ta == 3 && tc == 3) v = 0;   // constant term: not needed
+                            Pt[it][jt] = v;
+                        }
+                    }
+                    if (tP && k <= ckpt && pol && st_ok) {
+                        T *cp = tP + (size_t)k * TP_ROWS + r;
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
+                        }
+                    }
+                }
+                NMPC_WSYNC();
+            }
         }
         NMPC_STAMP(0)
         __syncthreads();   // L, m of every stage (written by lane 0) visible to the team
