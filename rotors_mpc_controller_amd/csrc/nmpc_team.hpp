@@ -15,7 +15,8 @@
 // Cholesky pivots use v_rsq_f64 + 2 Newton steps.
 //
 // Per-instance scratch in HBM is "array of structures" (a team reads contiguous runs):
-//   tLM [inst][stage][80] : M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | xhat (13) | pad
+//   tLM [inst][stage][160]: M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | xhat (13) | pad |
+//                           tile form of the FP64 path: Mbar^T tiles (64) | L^-1 tile (16)
 //   tIV [inst][stage][20] : u | lam_l | lam_u | u_aff | du   (4 each); during an active-set pass the last
 //                           two hold the candidate inputs and the pin codes (-1 lower, 0 free, +1 upper)
 //   tP  [inst][1 + ckpt][13][14] : (P_k, p_k), k = 1..ckpt, as left by an active-set pass.  The factorisation
@@ -33,7 +34,9 @@ namespace nmpc {
 
 constexpr int TEAM = 16;            // lanes per instance (one DPP row)
 constexpr int TEAMS_PER_WAVE = 4;
-constexpr int TLM_ROWS = 80;       // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad
+constexpr int TLM_ROWS = 160;      // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad (1) |
+                                   // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16)
+constexpr int TLM_MT = 80, TLM_Z = 144;
 constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
 constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
 constexpr int TP_ROWS = 256;        // per stage: 13 x 14 (VALU form) or 16 tiles x 16 lanes (MFMA form)
@@ -654,13 +657,17 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     M[jt] = mfma44(Y, X[jt], T(0));
                     if (st_ok && natC[jt] >= 0) lmk[natC[jt] * 4 + ta] = M[jt];
+                    // for the forward sweep: the same tile where the lane that needs it TRANSPOSED will read it
+                    if (st_ok) lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
                 }
+                if (st_ok) lmk[TLM_Z + r] = mfma44(Y, (ta == tc) ? T(1) : T(0), T(0));   // Y' = L^-1 as a tile
                 if (k > 0) {
                     // rows of Abar'(Pbar Abar): p rows copy, v rows add dt * p rows, q / omega rows are products
                     T qcol[4], qrow[4];
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) {
-                        qcol[t] = (tc == 3 && natR[t] >= 0) ? sh[natR[t] >= 0 ? natR[t] : 0] : T(0);
-                        qrow[t] = (ta == 3 && natC[t] >= 0) ? sh[natC[t] >= 0 ? natC[t] : 0] : T(0);
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) {      // unconditional reads + select: no exec-mask regions
+                        const T qa = sh[natR[t] >= 0 ? natR[t] : 0], qb = sh[natC[t] >= 0 ? natC[t] : 0];
+                        qcol[t] = (tc == 3 && natR[t] >= 0) ? qa : T(0);
+                        qrow[t] = (ta == 3 && natC[t] >= 0) ? qb : T(0);
                     }
                     T Pn[4][4];
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
@@ -719,6 +726,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
         // which this sweep sees by itself; only a pass with pins (or a violation to correct) needs sweep C
         T dirty = 0;
+        if constexpr (!MF) {
         prefetch_fwd(0);
         for (int k = 0; k < N; k++) {
             if (!SHARED) load_stage(k);
@@ -765,9 +773,96 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
+        if (cmpl) { sRed[4 + j] = rmax; sRed[8 + j] = s2; sRed[j] = dirty; }
+        } else {
+            // ---- tile form (FP64): xbar = [xhat;1] lives as four column tiles (element 4t+a in lane (a,0));
+            // v = Mbar xbar, u = -L^-T v and xbar+ = Abar xbar + B u are 17 v_mfma_f64_4x4x4 per stage
+            // on transposed tiles (the A operand is read transposed), with no LDS exchange at all.
+            const int ta = r >> 2, tc = r & 3;
+            int natR[4], natC[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) { natR[t] = nat_of(t, ta); natC[t] = nat_of(t, tc); }
+            const T lb_a = sel4(c.lbu, ta), ub_a = sel4(c.ubu, ta);
+            T AT2[4], AT3[4], BT[4];
+            auto load_tiles_T = [&]() {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    const int l = natC[it] >= 0 ? natC[it] : 0;
+                    const bool real = natC[it] >= 0;
+                    const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta], bv_ = sbv[l];
+                    AT2[it] = real ? a2 : T(0);                                   // Abar[4it+c][8+a]
+                    AT3[it] = real ? (ta < 3 ? a3 : bv_) : ((it == 3 && tc == 3 && ta == 3) ? T(1) : T(0));
+                    BT[it] = real ? bb : T(0);                                    // B[4it+c][a]
+                }
+            };
+            if (SHARED) load_tiles_T();
+            T xt[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+            // Per-stage operands (Mbar^T tiles, L^-1 tile, scalars of input a) come CHT stages at a time: a
+            // stage is a short chain of dependent MFMAs, shorter than an L2 round trip.
+            constexpr int CHT = 5;
+            for (int k0 = 0; k0 < N; k0 += CHT) {
+                T cMT[CHT][4], cZ[CHT], c_ul[CHT], c_pc[CHT], c_u[CHT], c_ll[CHT], c_lu[CHT];
+                NMPC_UNROLL for (int i = 0; i < CHT; i++) {
+                    const int k = (k0 + i < N) ? k0 + i : N - 1;
+                    const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMT[i][jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
+                    cZ[i] = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + ta); c_pc[i] = ivn[16 + ta];
+                    c_u[i] = 0; c_ll[i] = 0; c_lu[i] = 0;
+                    if (any_ipm) { c_u[i] = ivn[ta]; c_ll[i] = ivn[4 + ta]; c_lu[i] = ivn[8 + ta]; }
+                }
+                NMPC_UNROLL for (int i = 0; i < CHT; i++) {
+                    const int k = k0 + i;
+                    if (k < N) {
+                        if (!SHARED) { load_stage(k); load_tiles_T(); }
+                        T *ivk = tIV + k * IV_ROWS;
+                        const T ul = c_ul[i], pc = c_pc[i], u = c_u[i], ll = c_ll[i], lu = c_lu[i];
+                        if (pol2 && valid && tc == 0) {                              // xhat_k for the costate sweep
+                            NMPC_UNROLL for (int t = 0; t < 4; t++)
+                                if (natR[t] >= 0) tLM[k * TLM_ROWS + 66 + natR[t]] = xt[t];
+                        }
+                        // the part of Abar xbar that does not wait for u
+                        T xn[4];
+                        xn[0] = xt[0] + c.dt * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                        // v = Mbar xbar (two chains), u = -L^-T v
+                        const T v = mfma44(cMT[i][2], xt[2], mfma44(cMT[i][0], xt[0], T(0)))
+                                  + mfma44(cMT[i][3], xt[3], mfma44(cMT[i][1], xt[1], T(0)));
+                        const T ut = -mfma44(cZ[i], v, T(0));                         // lane (a,0): u_a
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+                        {
+                            const T uj = ut;
+                            if (tc == 0 && st_ok2) ivk[12 + ta] = uj;
+                            const T lo = lb_a - ul, hi = ub_a - ul;
+                            const T tol = c.kkt_tol * (T(1) + fabs(lo) + fabs(hi));
+                            const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
+                            dirty += (clean || tc != 0) ? T(0) : T(1);
+                            if (any_ipm) {
+                                const Pair<T> pr(u, ll, lu, lo, hi);
+                                const T d = uj - u;
+                                const T dla = -ll - pr.kl * d, dua = -lu + pr.ku * d;
+                                const T a1 = d * pr.itl, a2 = d * pr.itu;
+                                if (tc == 0) {
+                                    rmax = fmax(rmax, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
+                                    s2 += dla * d - dua * d;
+                                }
+                            }
+                        }
+                        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
+                    }
+                }
+            }
+            // back to one natural row per lane for the sweeps that follow
+            if (tc == 0) {
+                NMPC_UNROLL for (int t = 0; t < 4; t++)
+                    if (natR[t] >= 0) sXh[natR[t]] = xt[t];
+            }
+            NMPC_WSYNC();
+            xh = sXh[rr];
+            NMPC_WSYNC();
+            if (tc == 0) { sRed[4 + ta] = rmax; sRed[8 + ta] = s2; sRed[ta] = dirty; }
+        }
         NMPC_STAMP(1)
         if (pol2 && rowl && valid) tLM[66 + rr] = xh;     // xhat_N parks in the unused xhat_0 slot (final sweep)
-        if (cmpl) { sRed[4 + j] = rmax; sRed[8 + j] = s2; sRed[j] = dirty; }
         __syncthreads();
         rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
         s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
