@@ -644,7 +644,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                 }
                 l_solve(Lf, mv);
-                if (r == 0 && st_ok) {
+                // the natural-layout copies of L, m (and M below) feed the interior-point sweeps D/E only
+                if (any_ipm && r == 0 && st_ok) {
                     NMPC_UNROLL for (int i = 0; i < 10; i++) lmk[52 + i] = Lf[i];
                     NMPC_UNROLL for (int i = 0; i < NU; i++) lmk[62 + i] = mv[i];
                 }
@@ -656,7 +657,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T M[4];
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     M[jt] = mfma44(Y, X[jt], T(0));
-                    if (st_ok && natC[jt] >= 0) lmk[natC[jt] * 4 + ta] = M[jt];
+                    if (any_ipm && st_ok && natC[jt] >= 0) lmk[natC[jt] * 4 + ta] = M[jt];
                     // for the forward sweep: the same tile where the lane that needs it TRANSPOSED will read it
                     if (st_ok) lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
                 }
