@@ -180,6 +180,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     // v_mfma_f64_4x4x4_4b_f64 (operand/result element (a,c) of block b sits in lane 16a + 4b + c, probed
     // with tools/probe_mfma), so a 4x4 tile of a team's matrices is one register across the team.
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
+    // uniform constants of the hot loops, pinned to vector registers: as scalars they are spilled with
+    // their whole 16-dword kernel-argument tuple and re-read lane by lane inside every stage
+    T dt_v = c.dt, kkt_v = c.kkt_tol;
+    asm volatile("" : "+v"(dt_v), "+v"(kkt_v));
     const int rr = r < NX ? r : NX - 1;   // row used for loads; rows 13..15 shadow row 12 and never store
     const int j = r & 3;                  // input component handled by lanes r < 4 (others shadow)
     const bool rowl = r < NX, cmpl = r < NU;
@@ -234,11 +238,25 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         NMPC_UNROLL for (int l = 0; l < NX; l++) {
             const T zc = sAd[l * 8 + az];
             const T e = (l == rr) ? T(1) : T(0);
-            const T ev = (l == rr - 3) ? c.dt : T(0);
+            const T ev = (l == rr - 3) ? dt_v : T(0);
             Acol[l] = rr >= 6 ? zc : (rr >= 3 ? e + ev : e);
         }
     };
     if (SHARED) load_stage(0);
+    // Shared linearisation: the LDS copy stays valid for the whole kernel, so the row / column registers
+    // are re-read where a VALU-form sweep needs them instead of living across the (register-hungry)
+    // tile-form sweeps.
+    auto rows_from_lds = [&]() {
+        NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) Adrow[cc] = sAd[rr * 8 + cc];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) Brow[i] = sB[rr * 4 + i];
+        b_r = sbv[rr];
+        NMPC_UNROLL for (int l = 0; l < NX; l++) {
+            const T zc = sAd[l * 8 + az];
+            const T e = (l == rr) ? T(1) : T(0);
+            const T ev = (l == rr - 3) ? dt_v : T(0);
+            Acol[l] = rr >= 6 ? zc : (rr >= 3 ? e + ev : e);
+        }
+    };
 
     const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
     // ---- active-set guess of the first pass: everything free.  The interior point iterate itself is
@@ -406,7 +424,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                 }
             }
-            NMPC_UNROLL for (int i = 0; i < 3; i++) { PArow[i] = Prow[i]; PArow[3 + i] = c.dt * Prow[i] + Prow[3 + i]; }
+            NMPC_UNROLL for (int i = 0; i < 3; i++) { PArow[i] = Prow[i]; PArow[3 + i] = dt_v * Prow[i] + Prow[3 + i]; }
             NMPC_UNROLL for (int i = 0; i < NU; i++) { h += PBrow[i] * sD[12 + i]; PBrow[i] *= sD[8 + i]; }
             NMPC_UNROLL for (int i = 0; i < NU; i++) sPB[r * 4 + i] = PBrow[i];
             sh[r] = h;
@@ -485,12 +503,12 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 if (rr < 3) {
                     NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Pn[cc] = PArow[cc];
                 } else if (rr < 6) {
-                    NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Pn[cc] = PArow[cc] + c.dt * sPA[(rr - 3) * 14 + cc];
+                    NMPC_UNROLL for (int cc = 0; cc < NX; cc++) Pn[cc] = PArow[cc] + dt_v * sPA[(rr - 3) * 14 + cc];
                 } else {
                     NMPC_UNROLL for (int cc = 0; cc < 3; cc++) {
                         const T tp = sPA[cc * 14 + 6 + az];
                         Pn[cc] = tp;
-                        Pn[3 + cc] = sPA[(3 + cc) * 14 + 6 + az] + c.dt * tp;
+                        Pn[3 + cc] = sPA[(3 + cc) * 14 + 6 + az] + dt_v * tp;
                     }
                     NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) {
                         const int lo_ = az < cc ? az : cc, hi_ = az < cc ? cc : az;
@@ -609,7 +627,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T PA[4][4];
                 NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                     PA[kt][0] = Pt[kt][0];
-                    PA[kt][1] = c.dt * Pt[kt][0] + Pt[kt][1];
+                    PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
                     PA[kt][2] = W0[kt];
                     PA[kt][3] = W1[kt];
                 }
@@ -678,7 +696,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
                         }
                         Pn[0][jt] = PA[0][jt];
-                        Pn[1][jt] = c.dt * PA[0][jt] + PA[1][jt];
+                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt];
                         Pn[2][jt] = a2;
                         Pn[3][jt] = a3;
                     }
@@ -750,7 +768,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 if (cmpl && st_ok2) ivk[12 + j] = uj;
                 {
                     const T lo = lbj - ul, hi = ubj - ul;
-                    const T tol = c.kkt_tol * (T(1) + fabs(lo) + fabs(hi));
+                    const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
                     const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
                     dirty += clean ? T(0) : T(1);
                 }
@@ -767,7 +785,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (pol2 && rowl && valid) tLM[k * TLM_ROWS + 66 + rr] = xh;   // xhat_k for the costate sweep
             {   // also through the last stage: the active-set check needs xhat_N
                 T a = b_r;
-                a += (rr < 3) ? xh + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? xh : T(0));
+                a += (rr < 3) ? xh + dt_v * sXh[p * 16 + rr + 3] : (rr < 6 ? xh : T(0));
                 NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
                 NMPC_UNROLL for (int i = 0; i < NU; i++) a += Brow[i] * uh[i];
                 xh = a;
@@ -823,7 +841,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         }
                         // the part of Abar xbar that does not wait for u
                         T xn[4];
-                        xn[0] = xt[0] + c.dt * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+                        xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
                         NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
                         // v = Mbar xbar (two chains), u = -L^-T v
                         const T v = mfma44(cMT[i][2], xt[2], mfma44(cMT[i][0], xt[0], T(0)))
@@ -834,7 +852,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             const T uj = ut;
                             if (tc == 0 && st_ok2) ivk[12 + ta] = uj;
                             const T lo = lb_a - ul, hi = ub_a - ul;
-                            const T tol = c.kkt_tol * (T(1) + fabs(lo) + fabs(hi));
+                            const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
                             const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
                             dirty += (clean || tc != 0) ? T(0) : T(1);
                             if (any_ipm) {
@@ -889,6 +907,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // ================= sweep C (teams in an active-set pass): costates by the adjoint recursion,
         // KKT check of the pinned solve, corrected active set (primal-dual active-set step)
         if (__ballot(need_c) != 0) {
+            if (SHARED && MF) rows_from_lds();
             T pi_r = QdNr * xh + NMPC_TLD(w.qr, QRR, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
             int kchg = -1;           // highest stage whose pin set this check changes
@@ -923,11 +942,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         }
                         T npc;
                         if (pc != T(0)) {                                // multiplier sign of a pinned input
-                            const T tol = c.kkt_tol *(T(1) + fabs(g));
+                            const T tol = kkt_v *(T(1) + fabs(g));
                             const bool wrong = (pc < T(0) && g < -tol) || (pc > T(0) && g > tol);
                             npc = wrong ? T(0) : pc;
                         } else {                                         // free input inside its box?
-                            const T tol = c.kkt_tol *(T(1) + fabs(lo) + fabs(hi));
+                            const T tol = kkt_v *(T(1) + fabs(lo) + fabs(hi));
                             npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
                         }
                         chg += (npc != pc) ? T(1) : T(0);
@@ -960,6 +979,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (__ballot(ipm2) == 0) continue;   // nobody in this wave is iterating the interior point method
 
         // ================= sweep D: backward homogeneous solve
+        if (SHARED && MF) rows_from_lds();
         pv = 0;
         p = 0;
         T n_ua;
@@ -1047,7 +1067,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             if (k < N - 1) {
                 T a = 0;
-                a += (rr < 3) ? xh + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? xh : T(0));
+                a += (rr < 3) ? xh + dt_v * sXh[p * 16 + rr + 3] : (rr < 6 ? xh : T(0));
                 NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
                 NMPC_UNROLL for (int i = 0; i < NU; i++) a += Brow[i] * uh[i];
                 xh = a;
@@ -1136,7 +1156,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 }
             }
             outputs_done = true;
-        } else
+        } else {
+        if (SHARED && MF) rows_from_lds();
         for (int k0 = 0; k0 < N; k0 += CH) {
             T uv[CH], ulv[CH], xlv[CH];
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -1156,7 +1177,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     T du[NU];
                     NMPC_UNROLL for (int ii = 0; ii < NU; ii++) { du[ii] = sDr[p * 4 + ii]; bad |= !(du[ii] == du[ii]); }
                     T a = b_r;
-                    a += (rr < 3) ? dx + c.dt * sXh[p * 16 + rr + 3] : (rr < 6 ? dx : T(0));
+                    a += (rr < 3) ? dx + dt_v * sXh[p * 16 + rr + 3] : (rr < 6 ? dx : T(0));
                     NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
                     NMPC_UNROLL for (int ii = 0; ii < NU; ii++) a += Brow[ii] * du[ii];
                     dx = a;
@@ -1167,6 +1188,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     p ^= 1;
                 }
             }
+        }
         }
         if (!fast) {
             // NaN anywhere in the step poisons the instance: reduce the flag over the team
