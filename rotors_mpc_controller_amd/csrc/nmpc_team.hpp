@@ -815,6 +815,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (SHARED) load_tiles_T();
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+            int xslot[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = natR[t] >= 0 ? natR[t] : 13;   // 66 + 13 = the pad slot
             // Per-stage operands (Mbar^T tiles, L^-1 tile, scalars of input a) come CHT stages at a time: a
             // stage is a short chain of dependent MFMAs, shorter than an L2 round trip.
             constexpr int CHT = 5;
@@ -835,9 +837,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         if (!SHARED) { load_stage(k); load_tiles_T(); }
                         T *ivk = tIV + k * IV_ROWS;
                         const T ul = c_ul[i], pc = c_pc[i], u = c_u[i], ll = c_ll[i], lu = c_lu[i];
-                        if (pol2 && valid && tc == 0) {                              // xhat_k for the costate sweep
-                            NMPC_UNROLL for (int t = 0; t < 4; t++)
-                                if (natR[t] >= 0) tLM[k * TLM_ROWS + 66 + natR[t]] = xt[t];
+                        if (pol2 && valid && tc == 0) {          // xhat_k for the costate sweep (pads land in the spare slot)
+                            T *xs = tLM + k * TLM_ROWS + 66;
+                            NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
                         }
                         // the part of Abar xbar that does not wait for u
                         T xn[4];
