@@ -744,6 +744,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         };
         // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
         // which this sweep sees by itself; only a pass with pins (or a violation to correct) needs sweep C
+        // dirty: +1 per free input outside its box, +HEAVY per pinned input or NaN (a pass with only the
+        // former is corrected without costates: sweep C-light)
+        const T HEAVY = T(1048576);
         T dirty = 0;
         if constexpr (!MF) {
         prefetch_fwd(0);
@@ -770,7 +773,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     const T lo = lbj - ul, hi = ubj - ul;
                     const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
                     const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
-                    dirty += clean ? T(0) : T(1);
+                    dirty += clean ? T(0) : ((pc == T(0) && uj == uj) ? T(1) : HEAVY);
                 }
                 if (any_ipm) {
                     const Pair<T> pr(u, ll, lu, lbj - ul, ubj - ul);
@@ -856,7 +859,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             const T lo = lb_a - ul, hi = ub_a - ul;
                             const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
                             const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
-                            dirty += (clean || tc != 0) ? T(0) : T(1);
+                            dirty += (clean || tc != 0) ? T(0) : ((pc == T(0) && uj == uj) ? T(1) : HEAVY);
                             if (any_ipm) {
                                 const Pair<T> pr(u, ll, lu, lo, hi);
                                 const T d = uj - u;
@@ -887,11 +890,12 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         __syncthreads();
         rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
         s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
-        dirty = sRed[0] + sRed[1] + sRed[2] + sRed[3] + ((xh == xh) ? T(0) : T(1));
+        dirty = sRed[0] + sRed[1] + sRed[2] + sRed[3] + ((xh == xh) ? T(0) : HEAVY);
         sXh[r] = dirty;                                   // a NaN in any xhat_N row marks the whole team
         __syncthreads();
         NMPC_UNROLL for (int l = 0; l < NX; l++) dirty += sXh[l];
         const bool need_c = pol2 && (pol_fail || !(dirty == T(0)));
+        const bool heavy_c = need_c && (pol_fail || !(dirty < HEAVY));      // pins, NaN or a failed factorisation
         if (pol2 && !need_c) {                            // clean pass: the unconstrained solve is the QP solution
             npol++;
             pass_in_attempt++;
@@ -908,7 +912,41 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
 
         // ================= sweep C (teams in an active-set pass): costates by the adjoint recursion,
         // KKT check of the pinned solve, corrected active set (primal-dual active-set step)
-        if (__ballot(need_c) != 0) {
+        if (__ballot(heavy_c) == 0 && __ballot(need_c) != 0) {
+            // ---- sweep C-light: nothing was pinned, so there are no multipliers to check; the inputs that
+            // left their box are pinned there and the pass repeats (same outcome as the full sweep C)
+            T chg = 0;
+            int kchg = -1;
+            constexpr int CH = 10;
+            for (int k0 = N - 1; k0 >= 0; k0 -= CH) {
+                T c_ul[CH], c_uj[CH];
+                NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                    const int k = (k0 - i > 0) ? k0 - i : 0;
+                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = tIV[k * IV_ROWS + 12 + j];
+                }
+                NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                    const int k = k0 - i;
+                    if (k >= 0) {
+                        const T lo = lbj - c_ul[i], hi = ubj - c_ul[i], uj = c_uj[i];
+                        const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
+                        const T npc = uj < lo - tol ? T(-1) : (uj > hi + tol ? T(1) : T(0));
+                        chg += (npc != T(0)) ? T(1) : T(0);
+                        kchg = (npc != T(0) && kchg < 0) ? k : kchg;
+                        if (cmpl && need_c && valid) tIV[k * IV_ROWS + 16 + j] = npc;
+                    }
+                }
+            }
+            if (cmpl) { sRed[20 + j] = chg; sRed[28 + j] = (T)kchg; }
+            __syncthreads();
+            kchg = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
+            if (need_c) {
+                npol++;
+                pass_in_attempt++;
+                if (pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
+                else k_top = kchg < ckpt ? kchg : N - 1;
+            }
+            __syncthreads();
+        } else if (__ballot(need_c) != 0) {
             if (SHARED && MF) rows_from_lds();
             T pi_r = QdNr * xh + NMPC_TLD(w.qr, QRR, N * QR_ROWS + rr);   // xh = xhat_N after sweep B
             T chg = 0, nanf = (xh == xh) ? T(0) : T(1);
