@@ -241,14 +241,24 @@ def main() -> None:
             pmc = json.loads(pmc_file.read_text()).get(kname, {})
             if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-        roof = dict(bound="hbm", kernel="k_team_ipm" if args.mapping == "team" else "k_ipm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=hbm_alg_gbs / HBM_PEAK_GBS, traffic=traffic,
-                    traffic_source=(pmc_file.name if traffic is not None else None),
-                    kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"], prepare_ms=st["ms_prepare"], algorithmic_bytes_per_solve=alg_b,
-                    workspace_model_gbs=ws_gbs,
-                    alu=dict(achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak,
-                             flops_per_solve=flops, n_ipm_mean=n_ipm, n_kkt_rounds_mean=n_kkt,
-                             executed=dict(achieved=alu_x_tf, frac=alu_x_tf / f_peak, flops_per_solve=flops_x)))
+        kernel_name = "k_team_ipm" if args.mapping == "team" else "k_ipm"
+        hbm = dict(achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS,
+                   algorithmic_bytes_per_solve=alg_b, workspace_model_gbs=ws_gbs)
+        flop = dict(achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak,
+                    flops_per_solve=flops, n_ipm_mean=n_ipm, n_kkt_rounds_mean=n_kkt,
+                    executed=dict(achieved=alu_x_tf, frac=alu_x_tf / f_peak, flops_per_solve=flops_x))
+        # Which roof: by compulsory traffic the path is arithmetic bound (~130 flop/B against a machine
+        # balance of ~10).  The FP64 team kernel runs its factor and solve sweeps on v_mfma_f64_4x4x4 (the dense
+        # FP64 matrix peak of gfx950 equals the vector peak, 78.6 TFLOP/s), so that is the roof quoted for it;
+        # every other variant is a vector-ALU kernel and keeps the HBM line of the contract, with the flop
+        # figures beside it.  Both sub-objects are always present.
+        mfma_path = args.mapping == "team" and args.dtype == "f64" and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
+        common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else None),
+                      kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"], prepare_ms=st["ms_prepare"], hbm=hbm, alu=flop)
+        if mfma_path:
+            roof = dict(bound="mfma", achieved=alu_tf, peak=f_peak, unit="TFLOP/s", frac=alu_tf / f_peak, **common)
+        else:
+            roof = dict(bound="hbm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS, **common)
         line = dict(metric="NMPC SQP-RTI solves/sec (N=20, nx=13, nu=4) at batch=4096 per GPU",
                     value=rate, unit="solves/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=ms_step, device_ms_per_step=dev_ms, higher_is_better=True, scaling="weak",

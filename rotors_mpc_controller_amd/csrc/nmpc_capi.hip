@@ -1,8 +1,9 @@
 // nmpc_capi.hip -- HIP kernels (gfx950) and the C ABI of include/rotors_nmpc.h.
 //
-// Kernels: k_team_prepare / k_team_ipm (16 lanes per MPC instance, 4 instances per wave, default),
-// k_prepare / k_ipm (one instance per lane), k_cond_ipm (partial-condensing fidelity path) and the
-// element-wise kernels of nmpc_aux.hpp.  Every workgroup is one 64-lane wave, so a batch becomes
+// Kernels: k_team_ipm (16 lanes per MPC instance, 4 instances per wave; preparation fused in; FP64 Riccati
+// sweeps on v_mfma_f64_4x4x4 register tiles; the default), k_team_prepare (the same preparation as a
+// separate launch), k_prepare / k_ipm (one instance per lane), k_cond_ipm (partial-condensing fidelity
+// path) and the element-wise kernels of nmpc_aux.hpp.  Every workgroup is one 64-lane wave, so a batch becomes
 // hundreds to thousands of independent workgroups that the dispatcher spreads over all XCDs; no
 // inter-workgroup communication exists on this path (instances are independent), so no
 // release/acquire protocol is needed.

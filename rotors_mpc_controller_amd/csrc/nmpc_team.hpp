@@ -2,37 +2,40 @@
 //
 // Why: with one instance per lane a batch of 4096 is only 64 waves on a chip with 1024 SIMDs and
 // each wave streams ~40 KB of private workspace per instance through HBM/L2 -- measured
-// memory-latency bound (profiles/).  Here a wave holds 4 instances; lane r of a team
-// owns ROW r of the 13x13 Riccati matrix and of the stage matrices, the replicated operands
-// (B, the 7 dense columns of A, P*A, M) are exchanged through LDS, and one wave per workgroup
-// makes every exchange a single-wave hand-off.  B = 4096 -> 1024 waves = one per SIMD.
+// memory-latency bound (profiles/).  Here a wave holds 4 instances ("teams"); team b owns
+// lanes {16a + 4b + c}, lane (a,c) being row r = 4a + c of the 13x13 Riccati matrix and of the stage
+// matrices in the row-per-lane sweeps, and element (a,c) of every 4x4 register tile in the tile-form
+// sweeps (the FP64 factor and forward sweeps run on v_mfma_f64_4x4x4_4b_f64, whose block layout this
+// is).  One wave per workgroup makes every LDS exchange a single-wave hand-off.  B = 4096 -> 1024
+// waves = one per SIMD.
 //
 // Same algorithm and constants as lane_ipm() in nmpc_ipm.hpp and as the oracle; only the
 // distribution of the arithmetic over lanes differs ([UPSTREAM] HPIPM Riccati IPM, reached by
-// the reference through AcadosOcpSolver.solve(), controller.py:447).  Two arithmetic short-cuts
+// the reference through AcadosOcpSolver.solve(), controller.py:447).  Arithmetic short-cuts that
 // change results at rounding level only (tests hold 1e-9 against the oracle): slack reciprocals
-// (v_rcp_f64 + 2 Newton steps) replace the ~130 IEEE divisions per stage and iteration, and the
-// Cholesky pivots use v_rsq_f64 + 2 Newton steps.
+// (v_rcp_f64 + 2 Newton steps) replace the ~130 IEEE divisions per stage and iteration, the
+// Cholesky pivots use v_rsq_f64 + 2 Newton steps, and the tile form sums in MFMA order.
 //
 // Per-instance scratch in HBM is "array of structures" (a team reads contiguous runs):
 //   tLM [inst][stage][160]: M column-major [13][4] (52) | L packed, diagonal inverted (10) | m (4) | xhat (13) | pad |
 //                           tile form of the FP64 path: Mbar^T tiles (64) | L^-1 tile (16)
 //   tIV [inst][stage][20] : u | lam_l | lam_u | u_aff | du   (4 each); during an active-set pass the last
 //                           two hold the candidate inputs and the pin codes (-1 lower, 0 free, +1 upper)
-//   tP  [inst][1 + ckpt][13][14] : (P_k, p_k), k = 1..ckpt, as left by an active-set pass.  The factorisation
+//   tP  [inst][1 + ckpt][256] : (P_k, p_k), k = 1..ckpt, as left by an active-set pass (16 tiles x 16 lanes of
+//                           Pbar in the tile form, 13 rows of 14 in the row form).  The factorisation
 //                           of stage k depends on the pins of stages >= k only, so the next pass restarts its
 //                           backward sweep at the highest stage whose pin set changed - when that lies in the
 //                           checkpointed window (saturation sits in the first stages of the horizon) - instead
 //                           of at N-1.  The window bounds the store traffic: 1.4 KB per stage and instance
 //                           through a 64 B/clk store path cost 7 % of the sweep when every stage was kept.
-// Inputs of the stage matrices come from the SoA workspace written by k_prepare.
+// The stage matrices come from the per-instance block tAB written by team_prepare.
 #pragma once
 
 #include "nmpc_lane.hpp"
 
 namespace nmpc {
 
-constexpr int TEAM = 16;            // lanes per instance (one DPP row)
+constexpr int TEAM = 16;            // lanes per instance
 constexpr int TEAMS_PER_WAVE = 4;
 constexpr int TLM_ROWS = 160;      // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad (1) |
                                    // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16)
