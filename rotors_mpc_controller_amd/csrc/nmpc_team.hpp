@@ -37,9 +37,10 @@ namespace nmpc {
 
 constexpr int TEAM = 16;            // lanes per instance
 constexpr int TEAMS_PER_WAVE = 4;
-constexpr int TLM_ROWS = 160;      // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad (1) |
-                                   // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16)
-constexpr int TLM_MT = 80, TLM_Z = 144;
+constexpr int TLM_ROWS = 240;      // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad (1) |
+                                   // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16) |
+                                   // stages with pins: (B'Pbar Abar)^T unmasked (64) | (B'PB)^T (16)
+constexpr int TLM_MT = 80, TLM_Z = 144, TLM_G = 160;
 constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
 constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
 constexpr int TP_ROWS = 256;        // per stage: 13 x 14 (VALU form) or 16 tiles x 16 lanes (MFMA form)
@@ -299,6 +300,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu;
     int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
     int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
+    bool maybe_pins = false; // the current pin set may be non-empty (decides what the forward sweep prefetches)
     // per-team mode: interior point iteration, active-set (polish) pass, or finished
     enum { M_IPM = 0, M_POL = 1, M_DONE = 2 };
     int mode = valid ? M_IPM : M_DONE;      // idle teams never hold the wave back
@@ -311,7 +313,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (mode == M_IPM) {
             if (!(mu == mu)) { status = 1; mode = M_DONE; }
             else if (mu <= c.tol_comp && rho <= c.tol_stat) mode = M_DONE;
-            else if (c.polish && mu <= pol_mu && npol < c.polish_budget) { mode = M_POL; pass_in_attempt = 0; k_top = N - 1; }
+            else if (c.polish && mu <= pol_mu && npol < c.polish_budget) { mode = M_POL; pass_in_attempt = 0; k_top = N - 1; maybe_pins = it > 0; }
             else if (it >= c.iter_max) { status = 2; mode = M_DONE; }
         }
         if (__ballot(mode != M_DONE) == 0) break;
@@ -608,7 +610,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const T mask_a = sD[8 + ta], mask_c = sD[8 + tc], D_a = sD[ta], rhat_a = sD[4 + ta];
                 T Aq1[4];
                 NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
-                if (__ballot(pinned) != 0) {         // pinned inputs enter through b (column 15 of Abar)
+                const bool any_pins = __ballot(pinned) != 0;
+                if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
                     const T vp = sD[12 + tc];
                     NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                         const T sm = quad_sum(Bt[kt] * vp);
@@ -640,8 +643,12 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     T a = 0;
                     NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a);
                     X[jt] = mask_a * a;
+                    // gradient rows of the pinned inputs for the multiplier check of the forward sweep:
+                    // g = R u + r + B'PB (mask u) + B'(Pbar Abar) xbar, unmasked, stored transposed
+                    if (any_pins && st_ok) lmk[TLM_G + jt * 16 + tc * 4 + ta] = a;
                 }
                 NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
+                if (any_pins && st_ok) lmk[TLM_G + 64 + tc * 4 + ta] = Hr;
                 if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
                 const T Huu = ((ta == tc) ? D_a : T(0)) + mask_a * mask_c * Hr;
                 if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
@@ -821,16 +828,24 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (SHARED) load_tiles_T();
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+            int kchgB = -1;           // highest stage whose pin set this pass changes
+            const bool wave_pins = __ballot(pol2 && maybe_pins) != 0;
             int xslot[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = natR[t] >= 0 ? natR[t] : 13;   // 66 + 13 = the pad slot
             // Per-stage operands (Mbar^T tiles, L^-1 tile, scalars of input a) come CHT stages at a time: a
             // stage is a short chain of dependent MFMAs, shorter than an L2 round trip.
             constexpr int CHT = 5;
             for (int k0 = 0; k0 < N; k0 += CHT) {
-                T cMT[CHT][4], cZ[CHT], c_ul[CHT], c_pc[CHT], c_u[CHT], c_ll[CHT], c_lu[CHT];
+                T cMT[CHT][4], cZ[CHT], c_ul[CHT], c_pc[CHT], c_u[CHT], c_ll[CHT], c_lu[CHT], cG[CHT][5], c_rk[CHT];
                 NMPC_UNROLL for (int i = 0; i < CHT; i++) {
                     const int k = (k0 + i < N) ? k0 + i : N - 1;
                     const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+                    NMPC_UNROLL for (int g5 = 0; g5 < 5; g5++) cG[i][g5] = 0;
+                    c_rk[i] = 0;
+                    if (wave_pins) {               // gradient rows of the pinned inputs (stages without pins hold stale data)
+                        NMPC_UNROLL for (int g5 = 0; g5 < 5; g5++) cG[i][g5] = lmn[TLM_G + g5 * 16 + r];
+                        c_rk[i] = NMPC_TLD(w.qr, QRR, k * QR_ROWS + NX + ta);
+                    }
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMT[i][jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
                     cZ[i] = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
                     c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + ta); c_pc[i] = ivn[16 + ta];
@@ -857,12 +872,37 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         const T ut = -mfma44(cZ[i], v, T(0));                         // lane (a,0): u_a
                         NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
                         {
+                            // KKT check of the pass, input a in lane (a,0): a free input must sit inside its box; a
+                            // pinned one must have a multiplier of the right sign.  The costate is P x + p, so the
+                            // gradient of a pinned input comes from the rows the factor sweep left for this stage
+                            // and no adjoint sweep is needed; the corrected pin codes are written on the spot.
                             const T uj = ut;
-                            if (tc == 0 && st_ok2) ivk[12 + ta] = uj;
                             const T lo = lb_a - ul, hi = ub_a - ul;
-                            const T tol = kkt_v * (T(1) + fabs(lo) + fabs(hi));
-                            const bool clean = pc == T(0) && uj >= lo - tol && uj <= hi + tol;   // false for NaN
-                            dirty += (clean || tc != 0) ? T(0) : ((pc == T(0) && uj == uj) ? T(1) : HEAVY);
+                            const T vpin = pc < T(0) ? lo : hi;
+                            const bool pin_here = pol2 && pc != T(0);          // (interior-point teams keep other data there)
+                            const T ue = pin_here ? vpin : uj;               // pinned inputs sit exactly on the bound
+                            T npc;
+                            bool nanq = !(uj == uj);
+                            if (__ballot(tc == 0 && pin_here) != 0) {
+                                const T uf = (tc == 0 && !pin_here) ? ue : T(0);                    // mask u
+                                T g = mfma44(cG[i][4], uf, T(0));
+                                T g2 = mfma44(cG[i][1], xt[1], mfma44(cG[i][0], xt[0], T(0)));
+                                g = mfma44(cG[i][3], xt[3], mfma44(cG[i][2], xt[2], g));
+                                g += g2 + sel4(c.Rd, ta) * ue + c_rk[i];
+                                const T tolg = kkt_v * (T(1) + fabs(g));
+                                const bool wrong = (pc < T(0) && g < -tolg) || (pc > T(0) && g > tolg);
+                                const T tolb = kkt_v * (T(1) + fabs(lo) + fabs(hi));
+                                npc = pin_here ? (wrong ? T(0) : pc) : (uj < lo - tolb ? T(-1) : (uj > hi + tolb ? T(1) : T(0)));
+                                nanq |= !(g == g);
+                            } else {
+                                const T tolb = kkt_v * (T(1) + fabs(lo) + fabs(hi));
+                                npc = uj < lo - tolb ? T(-1) : (uj > hi + tolb ? T(1) : T(0));
+                            }
+                            if (tc == 0) {
+                                if (st_ok2) { ivk[12 + ta] = ue; if (pol2 && npc != pc) ivk[16 + ta] = npc; }
+                                dirty += nanq ? HEAVY : ((npc != pc) ? T(1) : T(0));
+                                kchgB = (npc != pc) ? k : kchgB;                  // ascending k: the last one is the highest
+                            }
                             if (any_ipm) {
                                 const Pair<T> pr(u, ll, lu, lo, hi);
                                 const T d = uj - u;
@@ -886,7 +926,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_WSYNC();
             xh = sXh[rr];
             NMPC_WSYNC();
-            if (tc == 0) { sRed[4 + ta] = rmax; sRed[8 + ta] = s2; sRed[ta] = dirty; }
+            if (tc == 0) { sRed[4 + ta] = rmax; sRed[8 + ta] = s2; sRed[ta] = dirty; sRed[28 + ta] = (T)kchgB; }
         }
         NMPC_STAMP(1)
         if (pol2 && rowl && valid) tLM[66 + rr] = xh;     // xhat_N parks in the unused xhat_0 slot (final sweep)
@@ -897,13 +937,21 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         sXh[r] = dirty;                                   // a NaN in any xhat_N row marks the whole team
         __syncthreads();
         NMPC_UNROLL for (int l = 0; l < NX; l++) dirty += sXh[l];
-        const bool need_c = pol2 && (pol_fail || !(dirty == T(0)));
-        const bool heavy_c = need_c && (pol_fail || !(dirty < HEAVY));      // pins, NaN or a failed factorisation
-        if (pol2 && !need_c) {                            // clean pass: the unconstrained solve is the QP solution
+        const bool unclean = pol2 && (pol_fail || !(dirty == T(0)));
+        if (pol2 && !unclean) {                           // the pass satisfies the KKT conditions of the QP: done
             npol++;
             pass_in_attempt++;
             mode = M_DONE; from_ua = true; mu = 0; rho = 0;
         }
+        if (MF && unclean) {                              // tile form: the forward sweep has already corrected the pins
+            const int kc = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
+            npol++;
+            pass_in_attempt++;
+            if (pol_fail || !(dirty < HEAVY) || pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
+            else { k_top = kc < ckpt ? kc : N - 1; maybe_pins = true; }
+        }
+        const bool need_c = !MF && unclean;
+        const bool heavy_c = need_c && (pol_fail || !(dirty < HEAVY));      // pins, NaN or a failed factorisation
         T sigmu;
         {
             const T aaff = T(1) / rmax;

@@ -21,13 +21,14 @@ import torch  # noqa: E402
 
 from rotors_mpc_controller_amd import _lib  # noqa: E402
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver  # noqa: E402
-from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0  # noqa: E402
+from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0  # noqa: E402
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
 ap.add_argument("--dtype", default="f64")
 ap.add_argument("--no-share", action="store_true")
 ap.add_argument("--mapping", default="team")
+ap.add_argument("--dist", default="near_hover")
 a = ap.parse_args()
 
 B = a.batch
@@ -36,7 +37,7 @@ cfg = _lib.default_config(max_batch=B, dtype=_lib.DTYPE_F64 if a.dtype == "f64" 
 if a.dtype == "f32":
     cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
 s = NmpcOcpSolver(cfg)
-x0 = sample_x0(B, 0, **NEAR_HOVER)
+x0 = sample_x0(B, 0, **(NEAR_HOVER if a.dist == "near_hover" else AGGRESSIVE))
 yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4)
 for _ in range(3):
     out = s.solve_batch(x0, yref, ye)
