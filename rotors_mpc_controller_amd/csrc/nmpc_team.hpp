@@ -1311,6 +1311,83 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
 
 
 // ---------------------------------------------------------------------------------------------------
+// Tile form of the model Jacobian (controller.py:267-355) for the forward sensitivities.  In the padded
+// order p_|v_|q|w_ the Jacobian has five non-zero 4x4 tiles: (p,v) = I, (v,q) = Fvq, (q,q) = Fqq,
+// (q,w) = Fqw, (w,w) = Fww.  Every entry is +-(0.5|1|2|k) times ONE state component, so lane (a,c) of a
+// team forms its element of each TRANSPOSED tile (what the MFMA wants as its A operand) as a dot product
+// of the state with a constant coefficient pattern; the patterns below are indexed by r = 4a + c and
+// restate model_jac() entry by entry (checked against it by the GPU parity tests).
+static __device__ const signed char NMPC_TVQ[16][4] = {   // Fvq[c][a] / t2 over (qw,qx,qy,qz)
+    {0, 0, 1, 0}, {0, -1, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0},
+    {0, 0, 0, 1}, {-1, 0, 0, 0}, {0, -2, 0, 0}, {0, 0, 0, 0},
+    {1, 0, 0, 0}, {0, 0, 0, 1}, {0, 0, -2, 0}, {0, 0, 0, 0},
+    {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+static __device__ const signed char NMPC_TQQ[16][3] = {   // Fqq[c][a] / 0.5 over (wx,wy,wz)
+    {0, 0, 0}, {1, 0, 0}, {0, 1, 0}, {0, 0, 1},
+    {-1, 0, 0}, {0, 0, 0}, {0, 0, -1}, {0, 1, 0},
+    {0, -1, 0}, {0, 0, 1}, {0, 0, 0}, {-1, 0, 0},
+    {0, 0, -1}, {0, -1, 0}, {1, 0, 0}, {0, 0, 0}};
+static __device__ const signed char NMPC_TQW[16][4] = {   // Fqw[c][a] / 0.5 over (qw,qx,qy,qz), a < 3
+    {0, -1, 0, 0}, {1, 0, 0, 0}, {0, 0, 0, 1}, {0, 0, -1, 0},
+    {0, 0, -1, 0}, {0, 0, 0, -1}, {1, 0, 0, 0}, {0, 1, 0, 0},
+    {0, 0, 0, -1}, {0, 0, 1, 0}, {0, -1, 0, 0}, {1, 0, 0, 0},
+    {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}, {0, 0, 0, 0}};
+static __device__ const signed char NMPC_TWW[16][3] = {   // Fww[c][a] / k_c over (wx,wy,wz), a, c < 3
+    {0, 0, 0}, {0, 0, 1}, {0, 1, 0}, {0, 0, 0},
+    {0, 0, 1}, {0, 0, 0}, {1, 0, 0}, {0, 0, 0},
+    {0, 1, 0}, {1, 0, 0}, {0, 0, 0}, {0, 0, 0},
+    {0, 0, 0}, {0, 0, 0}, {0, 0, 0}, {0, 0, 0}};
+
+template <class T>
+struct JacCoef {     // per-lane constants of the tile Jacobian
+    T vq[4], qq[3], qw[4], ww[3];   // coefficient patterns (ww already times k_c)
+    T fu;                           // f_u tile of the omega rows: fuw[a][c], a < 3
+};
+
+template <class T>
+__device__ __forceinline__ void jac_coef(const Consts<T> &c, int r, JacCoef<T> &k)
+{
+    const int ta = r >> 2, tc = r & 3;
+    NMPC_UNROLL for (int i = 0; i < 4; i++) { k.vq[i] = (T)NMPC_TVQ[r][i]; k.qw[i] = T(0.5) * (T)NMPC_TQW[r][i]; }
+    const T kx = -(c.J[2] - c.J[1]) * c.invJ[0], ky = -(c.J[0] - c.J[2]) * c.invJ[1], kz = -(c.J[1] - c.J[0]) * c.invJ[2];
+    const T kc = tc == 0 ? kx : (tc == 1 ? ky : kz);
+    NMPC_UNROLL for (int i = 0; i < 3; i++) { k.qq[i] = T(0.5) * (T)NMPC_TQQ[r][i]; k.ww[i] = kc * (T)NMPC_TWW[r][i]; }
+    T fu = 0;
+    NMPC_UNROLL for (int i = 0; i < 3; i++) {
+        NMPC_UNROLL for (int jj = 0; jj < NU; jj++) fu = (i == ta && jj == tc) ? c.fuw[i][jj] : fu;
+    }
+    k.fu = fu;
+}
+
+// the four transposed Jacobian tiles and the thrust-direction entry r3m[a] at state x, input u
+template <class T>
+__device__ __forceinline__ void jac_tiles(const Consts<T> &c, const JacCoef<T> &k, const T *x, const T *u, int ta,
+                                          T &FvqT, T &FqqT, T &FqwT, T &FwwT, T &r3a)
+{
+    const T qw = x[6], qx = x[7], qy = x[8], qz = x[9], wx = x[10], wy = x[11], wz = x[12];
+    const T t2 = T(2) * (u[0] + u[1] + u[2] + u[3]) * c.inv_mass;
+    FvqT = t2 * (k.vq[0] * qw + k.vq[1] * qx + k.vq[2] * qy + k.vq[3] * qz);
+    FqqT = k.qq[0] * wx + k.qq[1] * wy + k.qq[2] * wz;
+    FqwT = k.qw[0] * qw + k.qw[1] * qx + k.qw[2] * qy + k.qw[3] * qz;
+    FwwT = k.ww[0] * wx + k.ww[1] * wy + k.ww[2] * wz;
+    const T r0 = T(2) * (qx * qz + qw * qy) * c.inv_mass, r1 = T(2) * (qy * qz - qw * qx) * c.inv_mass,
+            r2 = (T(1) - T(2) * (qx * qx + qy * qy)) * c.inv_mass;
+    r3a = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : T(0)));
+}
+
+// K = J S + [0 | f_u]: S, K are 4 row tiles (p_, v_, q, w_) x 3 column tiles (q | w_ | u)
+template <class T>
+__device__ __forceinline__ void vde_tiles(T FvqT, T FqqT, T FqwT, T FwwT, T r3a, T fu, const T S[4][3], T K[4][3])
+{
+    NMPC_UNROLL for (int ct = 0; ct < 3; ct++) {
+        K[0][ct] = S[1][ct];
+        K[1][ct] = mfma44(FvqT, S[2][ct], ct == 2 ? r3a : T(0));
+        K[2][ct] = mfma44(FqwT, S[3][ct], mfma44(FqqT, S[2][ct], T(0)));
+        K[3][ct] = mfma44(FwwT, S[3][ct], ct == 2 ? fu : T(0));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Preparation phase in the team mapping (staging of controller.py:414-445 + linearisation, U2/U3):
 // lane r stages row r of every stage (coalesced 13- and 17-element runs of x0 / x_init / yref), and
 // lane c < 11 integrates column c of the forward sensitivities (4 quaternion, 3 body-rate, 4 input
@@ -1377,6 +1454,60 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     const int Ns = c.shared ? 1 : N;
     const int col = r < 11 ? r : 10;
     const bool is_u = col >= 7;
+    if constexpr (sizeof(T) == 8) {
+        // ---- tile form (FP64): the sensitivities are 4 x 3 register tiles, each VDE evaluation is 12
+        // v_mfma_f64_4x4x4 plus the four Jacobian tiles; no per-lane column logic, no Jacobian struct
+        const int ta = r >> 2, tc = r & 3;
+        int natR[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) natR[t] = nat_of(t, ta);
+        JacCoef<T> jk;
+        jac_coef(c, r, jk);
+        const T hh = T(0.5) * c.h;
+        for (int k = 0; k < Ns; k++) {
+            T xs[NX], us[NU], S[4][3];
+            NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (warm && k > 0) ? xi[(size_t)k * NX + i] : x0[i];
+            NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = warm ? ui[(size_t)k * NU + i] : T(0);
+            NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                NMPC_UNROLL for (int ct = 0; ct < 3; ct++) S[rt][ct] = 0;
+            }
+            S[2][0] = (ta == tc) ? T(1) : T(0);                  // d q / d q = I
+            S[3][1] = (ta == tc && ta < 3) ? T(1) : T(0);        // d w / d w = I
+            for (int st = 0; st < c.steps; st++) {
+                T f1[NX], xm[NX], f2[NX], K[4][3], Sm[4][3];
+                T a1, a2, a3, a4, a5;
+                model_f(c, xs, us, f1);
+                jac_tiles(c, jk, xs, us, ta, a1, a2, a3, a4, a5);
+                vde_tiles(a1, a2, a3, a4, a5, jk.fu, S, K);
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + hh * f1[i];
+                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                    NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[rt][ct] = S[rt][ct] + hh * K[rt][ct];
+                }
+                model_f(c, xm, us, f2);
+                jac_tiles(c, jk, xm, us, ta, a1, a2, a3, a4, a5);
+                vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm, K);
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += c.h * f2[i];
+                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                    NMPC_UNROLL for (int ct = 0; ct < 3; ct++) S[rt][ct] += c.h * K[rt][ct];
+                }
+            }
+            if (valid) {     // natural layout: Ad rows [13][8] | B rows [13][4] | b [13]
+                T *a = w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                    if (natR[rt] >= 0) {
+                        a[natR[rt] * 8 + tc] = S[rt][0];
+                        a[natR[rt] * 8 + 4 + tc] = tc < 3 ? S[rt][1] : T(0);
+                        a[104 + natR[rt] * NU + tc] = S[rt][2];
+                    }
+                }
+                if (rowl) {
+                    const T xn1 = (warm) ? xi[(size_t)(k + 1) * NX + rr] : x0[rr];
+                    T xnr = 0;
+                    NMPC_UNROLL for (int i = 0; i < NX; i++) xnr = (i == rr) ? xs[i] : xnr;
+                    a[156 + rr] = xnr - xn1;
+                }
+            }
+        }
+    } else
     for (int k = 0; k < Ns; k++) {
         T xs[NX], us[NU], S[NX];
         NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (warm && k > 0) ? xi[(size_t)k * NX + i] : x0[i];
