@@ -1442,12 +1442,22 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     const T x0r = x0[rr];
     constexpr int HC = 20, CH = 8;
     T hx[HC], hu[HC], hyx[HC], hyu[HC];
-    NMPC_UNROLL for (int i = 0; i < HC; i++) {
-        const int k = i < N ? i : N - 1;
-        hx[i] = (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r;         // stage 0 is pinned to x0
-        hu[i] = warm ? ui[(size_t)k * NU + j] : T(0);
-        hyx[i] = yr[(size_t)k * NY + rr];
-        hyu[i] = yr[(size_t)k * NY + NX + j];
+    if (warm) {                      // one wave-uniform branch instead of a select per stage and array
+        NMPC_UNROLL for (int i = 0; i < HC; i++) {
+            const int k = i < N ? i : N - 1;
+            hx[i] = k > 0 ? xi[(size_t)k * NX + rr] : x0r;              // stage 0 is pinned to x0
+            hu[i] = ui[(size_t)k * NU + j];
+            hyx[i] = yr[(size_t)k * NY + rr];
+            hyu[i] = yr[(size_t)k * NY + NX + j];
+        }
+    } else {
+        NMPC_UNROLL for (int i = 0; i < HC; i++) {
+            const int k = i < N ? i : N - 1;
+            hx[i] = x0r;
+            hu[i] = T(0);
+            hyx[i] = yr[(size_t)k * NY + rr];
+            hyu[i] = yr[(size_t)k * NY + NX + j];
+        }
     }
     const T xN = warm ? xi[(size_t)N * NX + rr] : x0r, yeN = ye[rr];
     // linearisation: one interval if the cold start lets all stages share it
@@ -1543,13 +1553,17 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
             }
         }
     }
-    NMPC_UNROLL for (int i = 0; i < HC; i++) {
-        if (i < N && valid) {
-            if (rowl) {
+    if (valid && rowl) {              // two exec-mask regions for all stages (stage bound: scalar branch)
+        NMPC_UNROLL for (int i = 0; i < HC; i++) {
+            if (i < N) {
                 NMPC_TST(w.xl, XLR, i * NX + rr, hx[i]);
                 NMPC_TST(w.qr, QRR, i * QR_ROWS + rr, Wqr * (hx[i] - hyx[i]));
             }
-            if (cmpl) {
+        }
+    }
+    if (valid && cmpl) {
+        NMPC_UNROLL for (int i = 0; i < HC; i++) {
+            if (i < N) {
                 NMPC_TST(w.ul, ULR, i * NU + j, hu[i]);
                 NMPC_TST(w.qr, QRR, i * QR_ROWS + NX + j, Wrj * (hu[i] - hyu[i]));
             }
