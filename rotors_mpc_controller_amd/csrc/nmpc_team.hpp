@@ -301,6 +301,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
     int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
     bool maybe_pins = false; // the current pin set may be non-empty (decides what the forward sweep prefetches)
+    int ck_valid = 0;        // checkpoints 1..ck_valid of this team are current
     // per-team mode: interior point iteration, active-set (polish) pass, or finished
     enum { M_IPM = 0, M_POL = 1, M_DONE = 2 };
     int mode = valid ? M_IPM : M_DONE;      // idle teams never hold the wave back
@@ -329,14 +330,25 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
         int ks = N - 1;
         if (tP) {
-            if (r == 0) sRed[28] = (T)(act ? (ipm ? N - 1 : k_top) : -1);
+            if (r == 0) { sRed[28] = (T)(act ? (ipm ? N - 1 : k_top) : -1); sRed[29] = (T)(act ? ck_valid : N); }
             __syncthreads();
             ks = 0;
+            int vmin = N;            // every live team must own the checkpoint the wave resumes from
             for (int t = 0; t < nteams; t++) {
-                const int kt = (int)smem[t * TEAM_LDS + L_RED + 28];
+                const int kt = (int)smem[t * TEAM_LDS + L_RED + 28], vt = (int)smem[t * TEAM_LDS + L_RED + 29];
                 ks = kt > ks ? kt : ks;
+                vmin = vt < vmin ? vt : vmin;
             }
+            if (ks >= vmin) ks = N - 1;
         }
+
+        // Checkpoint window of this pass: the first pass of an attempt keeps only the first two stages (almost
+        // every instance is done after it, and those that are not usually saturate in stage 0 or 1: writing
+        // 12 stages of tiles in every first pass cost 20 % of the throughput at B = 65536); corrected passes
+        // keep the configured window.  ck_valid tracks which checkpoints are current: stages this pass
+        // recomputes but does not store lose theirs.
+        const int wnd = pass_in_attempt == 0 ? (ckpt < 2 ? ckpt : 2) : ckpt;
+        if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
 
         // ================= sweep A: backward factorisation, affine right-hand side
         bool ok = true, nanp = false;
@@ -526,7 +538,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     Prow[cc] = a;
                 }
                 pv = pvn;
-                if (tP && k <= ckpt && pol && st_ok && rowl) {
+                if (tP && k <= wnd && pol && st_ok && rowl) {
                     T *cp = tP + ((size_t)k * NX + rr) * TP_ROW;
                     NMPC_UNROLL for (int cc = 0; cc < NX; cc++) cp[cc] = Prow[cc];
                     cp[NX] = pv;
@@ -720,7 +732,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             Pt[it][jt] = v;
                         }
                     }
-                    if (tP && k <= ckpt && pol && st_ok) {
+                    if (tP && k <= wnd && pol && st_ok) {
                         T *cp = tP + (size_t)k * TP_ROWS + r;
                         NMPC_UNROLL for (int it = 0; it < 4; it++) {
                             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
@@ -948,7 +960,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             npol++;
             pass_in_attempt++;
             if (pol_fail || !(dirty < HEAVY) || pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
-            else { k_top = kc < ckpt ? kc : N - 1; maybe_pins = true; }
+            else { k_top = kc < ck_valid ? kc : N - 1; maybe_pins = true; }
         }
         const bool need_c = !MF && unclean;
         const bool heavy_c = need_c && (pol_fail || !(dirty < HEAVY));      // pins, NaN or a failed factorisation
@@ -994,7 +1006,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 npol++;
                 pass_in_attempt++;
                 if (pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
-                else k_top = kchg < ckpt ? kchg : N - 1;
+                else k_top = kchg < ck_valid ? kchg : N - 1;
             }
             __syncthreads();
         } else if (__ballot(need_c) != 0) {
@@ -1063,7 +1075,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 pass_in_attempt++;
                 if (!pol_fail && xn == T(0) && chg == T(0)) { mode = M_DONE; from_ua = true; mu = 0; rho = 0; }
                 else if (pol_fail || !(xn == T(0)) || pass_in_attempt >= c.polish_passes) { mode = M_IPM; pol_mu *= T(1e-2); }
-                else k_top = kchg < ckpt ? kchg : N - 1;
+                else k_top = kchg < ck_valid ? kchg : N - 1;
             }
             __syncthreads();
         }
