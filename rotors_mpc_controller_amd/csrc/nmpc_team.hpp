@@ -650,10 +650,17 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     PA[kt][3] = W1[kt];
                 }
                 // X = B'(Pbar Abar) (column 15: B'h), Hr = B'PB
+                T X0raw = 0;
+                // (its p / v column tiles are transposes of tiles of Pbar B: X' = Abar' Pbar B, one MFMA with
+                // the identity each instead of four)
+                const T Idt = (ta == tc) ? T(1) : T(0);
                 T X[4], Hr = 0;
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     T a = 0;
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a);
+                    if (jt == 0) a = mfma44(WB[0], Idt, T(0));
+                    else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
+                    else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
+                    if (jt == 0) X0raw = a;
                     X[jt] = mask_a * a;
                     // gradient rows of the pinned inputs for the multiplier check of the forward sweep:
                     // g = R u + r + B'PB (mask u) + B'(Pbar Abar) xbar, unmasked, stored transposed
@@ -713,14 +720,20 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     T Pn[4][4];
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                         T a2 = 0, a3 = 0;
-                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                            a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                            a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                        if (jt >= 2) {
+                            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                                a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                                a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                            }
                         }
                         Pn[0][jt] = PA[0][jt];
                         Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt];
                         Pn[2][jt] = a2;
                         Pn[3][jt] = a3;
+                    }
+                    // the (q,w) x (p,v) tiles are the transposes of the (p,v) x (q,w) ones: an MFMA with the identity
+                    NMPC_UNROLL for (int it = 2; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
                     }
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
                         NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
