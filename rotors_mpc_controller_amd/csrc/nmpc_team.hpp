@@ -853,6 +853,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             if (SHARED) load_tiles_T();
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+            // the tile path has no costate sweep: xhat is only read back when the caller wants the state trajectory
+            const bool want_xhat = out.x_out != nullptr;
             int kchgB = -1;           // highest stage whose pin set this pass changes
             const bool wave_pins = __ballot(pol2 && maybe_pins) != 0;
             int xslot[4];
@@ -883,7 +885,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         if (!SHARED) { load_stage(k); load_tiles_T(); }
                         T *ivk = tIV + k * IV_ROWS;
                         const T ul = c_ul[i], pc = c_pc[i], u = c_u[i], ll = c_ll[i], lu = c_lu[i];
-                        if (pol2 && valid && tc == 0) {          // xhat_k for the costate sweep (pads land in the spare slot)
+                        if (want_xhat && pol2 && valid && tc == 0) {   // xhat_k for the final sweep (pads land in the spare slot)
                             T *xs = tLM + k * TLM_ROWS + 66;
                             NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
                         }
