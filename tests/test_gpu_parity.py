@@ -244,3 +244,44 @@ def test_riccati_checkpoint_restart_is_transparent(share):
         np.testing.assert_allclose(outs[ck]["x"], outs[0]["x"], rtol=0, atol=1e-12)
     ref = O.solve_batch(oracle_cfg(polish=True), x0, yref, ye)
     np.testing.assert_allclose(outs[12]["u0"], ref["u0"], rtol=0, atol=TOL_U)
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_tile_form_row_form_and_unfused_launch_agree(share, monkeypatch):
+    """The FP64 default (tile form on v_mfma_f64_4x4x4, preparation fused into the solve kernel) against
+    the row-per-lane form of the same sweeps (NMPC_TEAM_MFMA=0, what FP32 runs) and against the two-kernel
+    launch (NMPC_TEAM_FUSED=0): same algorithm, so the same solutions to rounding and - the multiplier
+    check differs only in how the gradient is formed - the same pass and iteration statistics."""
+    x0 = np.concatenate([sample_x0(256, 21, **AGGRESSIVE), sample_x0(128, 22, **WILD)])
+    outs = {}
+    for name, env in (("tile", {}), ("row", {"NMPC_TEAM_MFMA": "0"}), ("unfused", {"NMPC_TEAM_FUSED": "0"})):
+        for k in ("NMPC_TEAM_MFMA", "NMPC_TEAM_FUSED"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        s = make_solver(flags=(1 if share else 0) | _lib.FLAG_TEAM_MAPPING)      # the knobs are read at create
+        yref, ye = hover(s.config)
+        o = s.solve_batch(x0, yref, ye, want_traj=True)
+        st = s.stats()
+        o["stats"] = (st["polish_mean"], st["polish_max"], st["n_polished"], st["iter_mean"], st["iter_max"])
+        outs[name] = o
+    for name in ("row", "unfused"):
+        assert np.array_equal(outs[name]["status"], outs["tile"]["status"])
+        assert outs[name]["stats"] == outs["tile"]["stats"]
+        np.testing.assert_allclose(outs[name]["u"], outs["tile"]["u"], rtol=0, atol=1e-10)
+        np.testing.assert_allclose(outs[name]["x"], outs["tile"]["x"], rtol=0, atol=1e-9)
+
+
+def test_timing_switch_and_status_array():
+    """nmpc_set_timing(0): no events, times read 0, results unchanged; the kernel writes the caller's
+    status array itself."""
+    s = make_solver()
+    x0 = sample_x0(64, 3, **NEAR_HOVER)
+    yref, ye = hover(s.config)
+    a = s.solve_batch(x0, yref, ye)
+    t_on = s.stats()["ms_solve"]
+    s.set_timing(False)
+    b = s.solve_batch(x0, yref, ye)
+    st = s.stats()
+    assert t_on > 0 and st["ms_solve"] == 0 and st["batch"] == 64 and st["n_status"][0] == 64
+    assert np.array_equal(a["u0"], b["u0"]) and np.array_equal(a["status"], b["status"])
