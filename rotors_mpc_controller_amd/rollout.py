@@ -31,29 +31,59 @@ class ClosedLoopRollout:
         self.pos, self.yaw = z(B, 3), z(B)
         self.hover = cfg.mass * cfg.gravity / 4.0
 
-    def run(self, x0: np.ndarray, steps: int, setpoint=(0.0, 0.0, 1.0), yaw: float = 0.0):
-        """Returns host arrays xs [steps+1,B,13], us [steps,B,4]."""
+    def _tick(self, t: int, stream: int, warm: bool) -> None:
+        """One control tick on `stream`: solve (warm-started from the other trajectory buffer), plant step."""
+        s, B = self.s, self.B
+        cur, prev = t & 1, (t + 1) & 1
+        s.solve_batch_device(B, self.x.data_ptr(), self.yref.data_ptr(), self.yref_e.data_ptr(), False,
+                             self.u0.data_ptr(), status_ptr=self.status.data_ptr(),
+                             x_init_ptr=self.xt[prev].data_ptr() if warm else 0,
+                             u_init_ptr=self.ut[prev].data_ptr() if warm else 0,
+                             x_out_ptr=self.xt[cur].data_ptr(), u_out_ptr=self.ut[cur].data_ptr(), stream=stream)
+        s.plant_step_device(B, self.x.data_ptr(), self.u0.data_ptr(), self.xn.data_ptr(), True, stream)
+        self.x.copy_(self.xn)                   # fixed buffers: the tick can be replayed from a HIP graph
+
+    def run(self, x0: np.ndarray, steps: int, setpoint=(0.0, 0.0, 1.0), yaw: float = 0.0, log: bool = True,
+            use_graph: bool = False):
+        """Returns host arrays xs [steps+1,B,13], us [steps,B,4] (log=False: only the final state and input).
+
+        use_graph: after the cold first tick the loop is launch-bound (a tick is a fraction of a millisecond
+        of kernels), so two ticks - one per warm-start buffer parity - are captured into a HIP graph and
+        replayed; the library's per-solve timing events must be off (`solver.set_timing(False)`)."""
         torch, s, B = self.torch, self.s, self.B
-        stream = torch.cuda.current_stream().cuda_stream
         self.x.copy_(torch.as_tensor(np.ascontiguousarray(x0), dtype=self.dt_t))
         self.pos.copy_(torch.as_tensor(np.tile(np.asarray(setpoint, float), (B, 1)), dtype=self.dt_t))
         self.yaw.fill_(float(yaw))
-        s.build_hover_reference_device(B, self.pos.data_ptr(), self.yaw.data_ptr(), self.hover,
-                                       self.yref.data_ptr(), self.yref_e.data_ptr(), stream)
-        xs = torch.empty(steps + 1, B, 13, dtype=self.dt_t, device=self.x.device)
-        us = torch.empty(steps, B, 4, dtype=self.dt_t, device=self.x.device)
-        xs[0].copy_(self.x)
-        for t in range(steps):
-            cur, prev = t & 1, (t + 1) & 1
-            warm = t > 0
-            s.solve_batch_device(B, self.x.data_ptr(), self.yref.data_ptr(), self.yref_e.data_ptr(), False,
-                                 self.u0.data_ptr(), status_ptr=self.status.data_ptr(),
-                                 x_init_ptr=self.xt[prev].data_ptr() if warm else 0,
-                                 u_init_ptr=self.ut[prev].data_ptr() if warm else 0,
-                                 x_out_ptr=self.xt[cur].data_ptr(), u_out_ptr=self.ut[cur].data_ptr(), stream=stream)
-            s.plant_step_device(B, self.x.data_ptr(), self.u0.data_ptr(), self.xn.data_ptr(), True, stream)
-            us[t].copy_(self.u0)
-            self.x, self.xn = self.xn, self.x
-            xs[t + 1].copy_(self.x)
+        side = torch.cuda.Stream(self.x.device) if use_graph else torch.cuda.current_stream()
+        side.wait_stream(torch.cuda.current_stream())
+        xs = torch.empty(steps + 1 if log else 1, B, 13, dtype=self.dt_t, device=self.x.device)
+        us = torch.empty(steps if log else 1, B, 4, dtype=self.dt_t, device=self.x.device)
+        with torch.cuda.stream(side):
+            stream = side.cuda_stream
+            s.build_hover_reference_device(B, self.pos.data_ptr(), self.yaw.data_ptr(), self.hover,
+                                           self.yref.data_ptr(), self.yref_e.data_ptr(), stream)
+            if log:
+                xs[0].copy_(self.x)
+            graph = None
+            t = 0
+            while t < steps:
+                if use_graph and t >= 1 and (t & 1) == 1 and t + 2 <= steps and not log:
+                    if graph is None:
+                        graph = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(graph, stream=side):
+                            self._tick(t, side.cuda_stream, True)
+                            self._tick(t + 1, side.cuda_stream, True)
+                    graph.replay()
+                    t += 2
+                    continue
+                self._tick(t, stream, t > 0)
+                if log:
+                    us[t].copy_(self.u0)
+                    xs[t + 1].copy_(self.x)
+                t += 1
+            if not log:
+                xs[0].copy_(self.x)
+                us[0].copy_(self.u0)
+        torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         return xs.cpu().numpy().astype(np.float64), us.cpu().numpy().astype(np.float64)

@@ -123,3 +123,17 @@ def test_closed_loop_rollout_stays_on_device_and_converges_to_hover():
     err0 = np.linalg.norm(xs[0, :, 0:3] - [0, 0, 1.0], axis=1)
     err1 = np.linalg.norm(xs[-1, :, 0:3] - [0, 0, 1.0], axis=1)
     assert (err1 < 0.5 * err0 + 0.02).all()
+
+
+def test_closed_loop_hip_graph_replay_matches_eager_launches():
+    """The tick pair (solve + plant step, one per warm-start buffer parity) replayed from a HIP graph ends
+    in the same state and command as the eagerly launched loop."""
+    from rotors_mpc_controller_amd.rollout import ClosedLoopRollout
+    s = _solver(max_batch=64)
+    s.set_timing(False)                      # no event records inside the captured region
+    B, steps = 64, 21
+    x0 = sample_x0(B, 9, **NEAR_HOVER)
+    xs_e, us_e = ClosedLoopRollout(s, B).run(x0, steps)
+    xs_g, us_g = ClosedLoopRollout(s, B).run(x0, steps, log=False, use_graph=True)
+    np.testing.assert_allclose(xs_g[0], xs_e[-1], rtol=0, atol=1e-12)
+    np.testing.assert_allclose(us_g[0], us_e[-1], rtol=0, atol=1e-12)
