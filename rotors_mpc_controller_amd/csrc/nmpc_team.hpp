@@ -247,6 +247,21 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         }
     };
     if (SHARED) load_stage(0);
+    // per-stage linearisation in the tile sweeps: only the LDS copy is needed there, and its global loads
+    // are issued one stage ahead
+    T pfs[13];
+    auto fetch_stage = [&](int k) {
+        const T *a = w.tAB + ((size_t)inst * N + k) * TAB_ROWS;
+        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) pfs[cc] = a[rr * 8 + cc];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) pfs[8 + i] = a[104 + rr * NU + i];
+        pfs[12] = a[156 + rr];
+    };
+    auto put_stage = [&]() {
+        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) sAd[r * 8 + cc] = pfs[cc];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) sB[r * 4 + i] = pfs[8 + i];
+        sbv[r] = pfs[12];
+        NMPC_WSYNC();
+    };
     // Shared linearisation: the LDS copy stays valid for the whole kernel, so the row / column registers
     // are re-read where a VALU-form sweep needs them instead of living across the (register-hungry)
     // tile-form sweeps.
@@ -567,7 +582,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     Bt[kt] = real ? bb : T(0);
                 }
             };
-            if (SHARED) load_tiles();
+            if (SHARED) load_tiles(); else fetch_stage(ks);
             T Pt[4][4];
             if (ks == N - 1) {
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
@@ -591,7 +606,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
               n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
             if (any_ipm) { n_u = tIV[ks * IV_ROWS + j]; n_ll = tIV[ks * IV_ROWS + 4 + j]; n_lu = tIV[ks * IV_ROWS + 8 + j]; }
             for (int k = ks; k >= 0; k--) {
-                if (!SHARED) { load_stage(k); load_tiles(); }
+                if (!SHARED) { put_stage(); if (k > 0) fetch_stage(k - 1); load_tiles(); }
                 T *lmk = tLM + k * TLM_ROWS;
                 const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
                 if (k > 0) {
@@ -850,7 +865,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     BT[it] = real ? bb : T(0);                                    // B[4it+c][a]
                 }
             };
-            if (SHARED) load_tiles_T();
+            if (SHARED) load_tiles_T(); else fetch_stage(0);
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
             // the tile path has no costate sweep: xhat is only read back when the caller wants the state trajectory
@@ -882,7 +897,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int i = 0; i < CHT; i++) {
                     const int k = k0 + i;
                     if (k < N) {
-                        if (!SHARED) { load_stage(k); load_tiles_T(); }
+                        if (!SHARED) { put_stage(); if (k + 1 < N) fetch_stage(k + 1); load_tiles_T(); }
                         T *ivk = tIV + k * IV_ROWS;
                         const T ul = c_ul[i], pc = c_pc[i], u = c_u[i], ll = c_ll[i], lu = c_lu[i];
                         if (want_xhat && pol2 && valid && tc == 0) {   // xhat_k for the final sweep (pads land in the spare slot)
