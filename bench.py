@@ -79,8 +79,8 @@ def cpu_baseline(B_sample: int, N: int):
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
@@ -93,6 +93,8 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-solve-events", action="store_true",
                     help="keep the library's own HIP events around every solve inside the timed region")
+    ap.add_argument("--gather-every", type=int, default=8,
+                    help="multi-GPU: ticks whose u0 share one RCCL all-gather (1 = a collective per tick)")
     ap.add_argument("--no-polish", action="store_true", help="plain interior point iteration (qp_polish = 0)")
     ap.add_argument("--condensed", action="store_true", help="partial-condensing kernel (NMPC_FLAG_CONDENSED_QP)")
     ap.add_argument("--polish-ckpt", type=int, default=None, help="override nmpc_config.qp_polish_ckpt")
@@ -148,33 +150,48 @@ def main() -> None:
     else:
         yref = torch.from_numpy(np.tile(yref_h, (B, 1, 1)).astype(npdt)).to(dev).contiguous()
         yref_e = torch.from_numpy(np.tile(yref_e_h, (B, 1)).astype(npdt)).to(dev).contiguous()
-    # two command buffers: the RCCL gather of tick i (own stream) overlaps the solve of tick i+1
-    u0s = [torch.zeros(B, 4, dtype=tdt, device=dev) for _ in range(2)]
-    u0 = u0s[0]
+    # Command buffers: G consecutive ticks fill one group [G][B][4]; a full group is gathered by ONE
+    # asynchronous RCCL all-gather (own stream) while the next group is being solved into the other
+    # buffer.  A 0.1 ms step is launch-bound on the host side of a collective (enqueue + bookkeeping cost
+    # about as much as the solve itself), so the u0 exchange is batched: fewer, larger collectives over
+    # the point-to-point xGMI links.  Every tick's u0 is gathered; --gather-every 1 restores one per tick.
+    G = max(1, args.gather_every)
+    u0g = [torch.zeros(G, B, 4, dtype=tdt, device=dev) for _ in range(2)]
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     xo = torch.zeros(B, N + 1, 13, dtype=tdt, device=dev) if args.traj_out else None
     uo = torch.zeros(B, N, 4, dtype=tdt, device=dev) if args.traj_out else None
-    gathered = [torch.zeros(world * B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
+    gathered = [torch.zeros(world, G, B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
     pending = [None, None]
     stream = torch.cuda.current_stream(dev)
     tick = [0]
+    last = [0, 0]                                                # (group buffer, slot) of the latest solve
+
+    def flush(k):
+        pending[k] = dist.all_gather_into_tensor(gathered[k].view(world * G * B, 4), u0g[k].view(G * B, 4), async_op=True)
 
     def step():
-        k = tick[0] & 1
+        t = tick[0]
         tick[0] += 1
-        if use_dist and pending[k] is not None:
-            pending[k].wait()                                   # buffer k's previous gather must have drained
+        k, slot = (t // G) & 1, t % G
+        if use_dist and slot == 0 and pending[k] is not None:
+            pending[k].wait()                                   # group k's previous gather must have drained
             pending[k] = None
-        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0s[k].data_ptr(),
+        last[0], last[1] = k, slot
+        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0g[k][slot].data_ptr(),
                                   status_ptr=status.data_ptr(),
                                   x_out_ptr=xo.data_ptr() if xo is not None else 0,
                                   u_out_ptr=uo.data_ptr() if uo is not None else 0,
                                   stream=stream.cuda_stream)
-        if use_dist:                                            # RCCL over xGMI, asynchronous to the next solve
-            pending[k] = dist.all_gather_into_tensor(gathered[k], u0s[k], async_op=True)
+        if use_dist and slot == G - 1:                          # RCCL over xGMI, asynchronous to the next group
+            flush(k)
 
     def fence():
         if use_dist:
+            t = tick[0]
+            if t % G != 0:                                      # a partly filled group: gather it as well
+                k = (t // G) & 1
+                flush(k)
+                tick[0] = (t // G + 1) * G
             for k in (0, 1):
                 if pending[k] is not None:
                     pending[k].wait()
@@ -206,9 +223,9 @@ def main() -> None:
     step()
     fence()
     st = solver.stats()                                          # HIP events of one extra, untimed step
-    u0_h = u0s[(tick[0] - 1) & 1].cpu().numpy().astype(np.float64)
+    u0_h = u0g[last[0]][last[1]].cpu().numpy().astype(np.float64)
     if use_dist:                                                 # the gathered block of this rank is its own u0
-        g = gathered[(tick[0] - 1) & 1][rank * B:(rank + 1) * B].cpu().numpy().astype(np.float64)
+        g = gathered[last[0]][rank, last[1]].cpu().numpy().astype(np.float64)
         assert np.array_equal(g, u0_h), "all-gather returned a different u0 block"
     status_h = status.cpu().numpy()
 
@@ -266,7 +283,7 @@ def main() -> None:
                     config=dict(workload=f"batch={B} random x0 around hover ({args.dist}, seed {seed}), N={N}, "
                                          f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
                                 batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
-                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather u0"),
+                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks"),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
                     active_set_passes=dict(mean=st["polish_mean"], max=st["polish_max"], accepted=st["n_polished"]),
                     status_histogram=st["n_status"], roofline=roof)
