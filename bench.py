@@ -5,8 +5,9 @@ Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N>1 it i
 torch.distributed.run with one rank per GPU.  Prints ONE JSON line on rank 0.
 
 A "step" = one batch of B independent NMPC instances solved start to finish (linearise ->
-interior-point QP -> full SQP step) with the inputs already resident in HBM, followed - when
-N>1 - by the RCCL all-gather of the first-stage commands u0 (the only exchange the path has).
+active-set / interior-point QP -> full SQP step) with the inputs already resident in HBM; when N>1
+the first-stage commands u0 (the only exchange the path has) are moved by RCCL all-gathers, one per
+group of --gather-every consecutive ticks, asynchronously to the following solves.
 Workload = BASELINE.json configs[1]: B = 4096 near-hover initial states per GPU, horizon 20,
 FP64, hover reference materialised per instance ([B,N,17]).
 """
