@@ -732,33 +732,34 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         qcol[t] = (tc == 3 && natR[t] >= 0) ? qa : T(0);
                         qrow[t] = (ta == 3 && natC[t] >= 0) ? qb : T(0);
                     }
+                    // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled inside the matrix pipe: Qbar (stage
+                    // Hessian diagonal, q_k in row / column 15) seeds the accumulators, -Mbar'Mbar is the last
+                    // accumulation, so the result tiles never pass through the vector ALU.  (Element [15][15], the
+                    // constant of the cost-to-go, just accumulates: nothing reads it.)
                     T Pn[4][4];
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                        T a2 = 0, a3 = 0;
+                        T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
+                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                                 a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
                                 a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
                             }
                         }
-                        Pn[0][jt] = PA[0][jt];
-                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt];
+                        Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
+                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0));
                         Pn[2][jt] = a2;
                         Pn[3][jt] = a3;
                     }
-                    // the (q,w) x (p,v) tiles are the transposes of the (p,v) x (q,w) ones: an MFMA with the identity
+                    // the (q,w) x (p,v) tiles are the transposes of the (p,v) x (q,w) ones (Qbar included: it is
+                    // symmetric): an MFMA with the identity
                     NMPC_UNROLL for (int it = 2; it < 4; it++) {
                         NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
                     }
+                    T Mn[4];
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M[t];
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                            T v = Pn[it][jt] - mfma44(M[it], M[jt], T(0));
-                            if (it == jt) v += Qdg[it];
-                            if (jt == 3) v += qcol[it];
-                            if (it == 3) v += qrow[jt];
-                            if (it == 3 && jt == 3 && ta == 3 && tc == 3) v = 0;   // constant term: not needed
-                            Pt[it][jt] = v;
-                        }
+                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
                     }
                     if (tP && k <= wnd && pol && st_ok) {
                         T *cp = tP + (size_t)k * TP_ROWS + r;
