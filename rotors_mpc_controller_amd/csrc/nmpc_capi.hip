@@ -70,10 +70,10 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const long long t_entry = NMPC_PROF_NOW();
     if (fused) {
-        team_prepare(c, w, in, B, tpw);
+        team_prepare(c, w, in, B, tpw, reinterpret_cast<T *>(smem_raw));
         __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
     }
-    team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry);
+    team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry, SHARED && fused != 0);
 }
 
 }  // namespace

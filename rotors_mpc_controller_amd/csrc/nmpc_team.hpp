@@ -178,7 +178,8 @@ struct Pair {
 // that the per-stage reload code and its address arithmetic do not exist in the shared variant
 template <class T, bool BATCH, bool SHARED, bool MF>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
-                                         const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0)
+                                         const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0,
+                                         bool lds_prefilled = false)
 {
     // lane -> (team, row): team b owns lanes {16a + 4b + c}, row r = 4a + c.  This is the block layout of
     // v_mfma_f64_4x4x4_4b_f64 (operand/result element (a,c) of block b sits in lane 16a + 4b + c, probed
@@ -246,7 +247,6 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             Acol[l] = rr >= 6 ? zc : (rr >= 3 ? e + ev : e);
         }
     };
-    if (SHARED) load_stage(0);
     // per-stage linearisation in the tile sweeps: only the LDS copy is needed there, and its global loads
     // are issued one stage ahead
     T pfs[13];
@@ -276,6 +276,11 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             Acol[l] = rr >= 6 ? zc : (rr >= 3 ? e + ev : e);
         }
     };
+
+    if (SHARED) {
+        if (lds_prefilled) rows_from_lds();     // the fused preparation left the stage matrices in LDS
+        else load_stage(0);
+    }
 
     const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
     // ---- active-set guess of the first pass: everything free.  The interior point iterate itself is
@@ -1459,8 +1464,11 @@ __device__ __forceinline__ void vde_col_rt(const Consts<T> &c, const Jac<T> &J, 
 }
 
 template <class T>
-__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B, int tpw)
+__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B, int tpw,
+                                             T *smem = nullptr)
 {
+    // smem != null (fused launch) and a shared cold-start linearisation: the stage matrices go straight
+    // into the team's LDS arrays (natural layout, as load_stage leaves them) and never touch HBM
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
     const int rr = r < NX ? r : NX - 1, j = r & 3;
     const bool rowl = r < NX, cmpl = r < NU;
@@ -1543,20 +1551,22 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
                     NMPC_UNROLL for (int ct = 0; ct < 3; ct++) S[rt][ct] += c.h * K[rt][ct];
                 }
             }
-            if (valid) {     // natural layout: Ad rows [13][8] | B rows [13][4] | b [13]
-                T *a = w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+            const bool to_lds = smem != nullptr && c.shared;
+            if (valid || to_lds) {     // natural layout: Ad rows [13][8] | B rows [13][4] | b [13]
+                T *a = to_lds ? smem + team * TEAM_LDS : w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+                const int oA = to_lds ? L_AD : 0, oB = to_lds ? L_B : 104, ob = to_lds ? L_BV : 156;
                 NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
                     if (natR[rt] >= 0) {
-                        a[natR[rt] * 8 + tc] = S[rt][0];
-                        a[natR[rt] * 8 + 4 + tc] = tc < 3 ? S[rt][1] : T(0);
-                        a[104 + natR[rt] * NU + tc] = S[rt][2];
+                        a[oA + natR[rt] * 8 + tc] = S[rt][0];
+                        a[oA + natR[rt] * 8 + 4 + tc] = tc < 3 ? S[rt][1] : T(0);
+                        a[oB + natR[rt] * NU + tc] = S[rt][2];
                     }
                 }
                 if (rowl) {
                     const T xn1 = (warm) ? xi[(size_t)(k + 1) * NX + rr] : x0[rr];
                     T xnr = 0;
                     NMPC_UNROLL for (int i = 0; i < NX; i++) xnr = (i == rr) ? xs[i] : xnr;
-                    a[156 + rr] = xnr - xn1;
+                    a[ob + rr] = xnr - xn1;
                 }
             }
         }
@@ -1580,19 +1590,21 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
             vde_col_rt(c, J2, sm, k2, is_u, col - 7);
             NMPC_UNROLL for (int i = 0; i < NX; i++) S[i] += c.h * k2[i];
         }
-        if (valid) {
-            T *a = w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+        const bool to_lds = smem != nullptr && c.shared;
+        if (valid || to_lds) {
+            T *a = to_lds ? smem + team * TEAM_LDS : w.tAB + ((size_t)inst * Ns + k) * TAB_ROWS;
+            const int oA = to_lds ? L_AD : 0, oB = to_lds ? L_B : 104, ob = to_lds ? L_BV : 156;
             if (r < 7) {
-                NMPC_UNROLL for (int i = 0; i < NX; i++) a[i * 8 + r] = S[i];
+                NMPC_UNROLL for (int i = 0; i < NX; i++) a[oA + i * 8 + r] = S[i];
             } else if (r < 11) {
-                NMPC_UNROLL for (int i = 0; i < NX; i++) a[104 + i * NU + (r - 7)] = S[i];
+                NMPC_UNROLL for (int i = 0; i < NX; i++) a[oB + i * NU + (r - 7)] = S[i];
             }
             if (rowl) {
-                a[rr * 8 + 7] = 0;
+                a[oA + rr * 8 + 7] = 0;
                 const T xn1 = (warm) ? xi[(size_t)(k + 1) * NX + rr] : x0[rr];
                 T xnr = 0;
                 NMPC_UNROLL for (int i = 0; i < NX; i++) xnr = (i == rr) ? xs[i] : xnr;
-                a[156 + rr] = xnr - xn1;
+                a[ob + rr] = xnr - xn1;
             }
         }
     }
