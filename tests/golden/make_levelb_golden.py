@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Runs the UNMODIFIED reference controller (/root/reference/src/rotors_mpc_controller/controller.py)
-on top of the Level-B shims (tools/levelb) with the CPU oracle as backend, and records what it
+on top of the Level-B shims (tests/levelb) with the CPU oracle as backend, and records what it
 receives and returns over a short closed loop: tests/golden/levelb_closed_loop.npz.
 
 What this pins: the reference's own staging code (quaternion normalisation, x0 pin, cold / unshifted
@@ -17,7 +17,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent.parent
 sys.path.insert(0, str(ROOT))
-sys.path.insert(0, str(ROOT / "tools" / "levelb"))
+sys.path.insert(0, str(ROOT / "tests" / "levelb"))
 REF = Path("/root/reference/src/rotors_mpc_controller")
 
 

@@ -1,5 +1,5 @@
 """Stand-in for the three names the reference imports from acados_template (controller.py:15):
-AcadosModel, AcadosOcp, AcadosOcpSolver.  Written from scratch; see tools/levelb/README.md.
+AcadosModel, AcadosOcp, AcadosOcpSolver.  Written from scratch; see tests/levelb/README.md.
 
 AcadosOcpSolver understands exactly the OCP that controller.py:175-264 builds (LINEAR_LS cost with
 y = [x;u], input box bounds, pinned initial state, ERK 2x2, Gauss-Newton, LM) and refuses anything

@@ -1,5 +1,5 @@
 """Minimal symbolic tracer standing in for the parts of CasADi that the reference's
-controller.py:267-355 touches.  Written from scratch; see tools/levelb/README.md."""
+controller.py:267-355 touches.  Written from scratch; see tests/levelb/README.md."""
 from __future__ import annotations
 
 import numpy as np
