@@ -294,7 +294,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         constexpr int CHI = 10;
         for (int k0 = 0; k0 < N; k0 += CHI) {
             T ulv[CHI];
-            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = NMPC_TLD(w.ul, ULR, ((k0 + i < N) ? k0 + i : N - 1) * NU + j);
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ((k0 + i < N) ? k0 + i : N - 1) * NU + j);
             NMPC_UNROLL for (int i = 0; i < CHI; i++) {
                 const int k = k0 + i;
                 const T lo = lbj - ulv[i], hi = ubj - ulv[i];
@@ -386,7 +386,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             pv = cp[NX];
         }
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j);
+        n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ks * NU + j);
         n_pc = tIV[ks * IV_ROWS + 16 + j];
         T n_u = 0, n_ll = 0, n_lu = 0,
           n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
@@ -397,7 +397,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
             if (k > 0) {
                 const T *ivn = tIV + (k - 1) * IV_ROWS;
-                n_ul = NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
                 if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
                 n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
             }
@@ -605,7 +605,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
                 }
             }
-            n_ul = NMPC_TLD(w.ul, ULR, ks * NU + j);
+            n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ks * NU + j);
             n_pc = tIV[ks * IV_ROWS + 16 + j];
             T n_u = 0, n_ll = 0, n_lu = 0,
               n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
@@ -616,7 +616,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
                 if (k > 0) {
                     const T *ivn = tIV + (k - 1) * IV_ROWS;
-                    n_ul = NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                    n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
                     if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
                     n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
                 }
@@ -896,7 +896,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMT[i][jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
                     cZ[i] = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
-                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + ta); c_pc[i] = ivn[16 + ta];
+                    c_ul[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, k * NU + ta); c_pc[i] = ivn[16 + ta];
                     c_u[i] = 0; c_ll[i] = 0; c_lu[i] = 0;
                     if (any_ipm) { c_u[i] = ivn[ta]; c_ll[i] = ivn[4 + ta]; c_lu[i] = ivn[8 + ta]; }
                 }
@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T c_ul[CH], c_uj[CH];
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = (k0 - i > 0) ? k0 - i : 0;
-                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = tIV[k * IV_ROWS + 12 + j];
+                    c_ul[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = tIV[k * IV_ROWS + 12 + j];
                 }
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = k0 - i;
