@@ -93,6 +93,8 @@ struct TeamWork {
 // the same buffers as [row][Bp], which is what coalesces for one instance per lane).
 #define NMPC_TLD(p, rows, row) ((p)[(size_t)inst * (size_t)(rows) + (size_t)(row)])
 #define NMPC_TST(p, rows, row, v) ((p)[(size_t)inst * (size_t)(rows) + (size_t)(row)] = (v))
+// linearisation input u_k: identically zero under the shared cold start (nothing is staged for it then)
+#define NMPC_UL0(row) (SHARED ? T(0) : NMPC_TLD(w.ul, ULR, row))
 
 // hard fence for the machine scheduler: nothing is moved across it (used to keep LDS reads batched)
 #define NMPC_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -294,7 +296,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         constexpr int CHI = 10;
         for (int k0 = 0; k0 < N; k0 += CHI) {
             T ulv[CHI];
-            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ((k0 + i < N) ? k0 + i : N - 1) * NU + j);
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = NMPC_UL0( ((k0 + i < N) ? k0 + i : N - 1) * NU + j);
             NMPC_UNROLL for (int i = 0; i < CHI; i++) {
                 const int k = k0 + i;
                 const T lo = lbj - ulv[i], hi = ubj - ulv[i];
@@ -386,7 +388,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             pv = cp[NX];
         }
         // software prefetch of the next stage's scalars (global loads stay in flight over the stage)
-        n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ks * NU + j);
+        n_ul = NMPC_UL0( ks * NU + j);
         n_pc = tIV[ks * IV_ROWS + 16 + j];
         T n_u = 0, n_ll = 0, n_lu = 0,
           n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
@@ -397,7 +399,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
             if (k > 0) {
                 const T *ivn = tIV + (k - 1) * IV_ROWS;
-                n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                n_ul = NMPC_UL0( (k - 1) * NU + j); n_pc = ivn[16 + j];
                 if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
                 n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
             }
@@ -605,7 +607,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
                 }
             }
-            n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, ks * NU + j);
+            n_ul = NMPC_UL0( ks * NU + j);
             n_pc = tIV[ks * IV_ROWS + 16 + j];
             T n_u = 0, n_ll = 0, n_lu = 0,
               n_rk = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + NX + j), n_qr = NMPC_TLD(w.qr, QRR, ks * QR_ROWS + rr);
@@ -616,7 +618,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const T ul = n_ul, u = n_u, ll = n_ll, lu = n_lu, rk = n_rk, q_r = n_qr, pc = n_pc;
                 if (k > 0) {
                     const T *ivn = tIV + (k - 1) * IV_ROWS;
-                    n_ul = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, (k - 1) * NU + j); n_pc = ivn[16 + j];
+                    n_ul = NMPC_UL0( (k - 1) * NU + j); n_pc = ivn[16 + j];
                     if (any_ipm) { n_u = ivn[j]; n_ll = ivn[4 + j]; n_lu = ivn[8 + j]; }
                     n_rk = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + NX + j); n_qr = NMPC_TLD(w.qr, QRR, (k - 1) * QR_ROWS + rr);
                 }
@@ -795,7 +797,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) { nM[i] = lmn[rr * 4 + i]; nm[i] = lmn[62 + i]; }
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_TLD(w.ul, ULR, k * NU + j); n_pc = ivn[16 + j];
+            n_ul = NMPC_UL0( k * NU + j); n_pc = ivn[16 + j];
             if (any_ipm) { n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; }
         };
         // active-set pass: with nothing pinned the KKT conditions reduce to "every input inside its box",
@@ -896,7 +898,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMT[i][jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
                     cZ[i] = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
-                    c_ul[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, k * NU + ta); c_pc[i] = ivn[16 + ta];
+                    c_ul[i] = NMPC_UL0( k * NU + ta); c_pc[i] = ivn[16 + ta];
                     c_u[i] = 0; c_ll[i] = 0; c_lu[i] = 0;
                     if (any_ipm) { c_u[i] = ivn[ta]; c_ll[i] = ivn[4 + ta]; c_lu[i] = ivn[8 + ta]; }
                 }
@@ -1021,7 +1023,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T c_ul[CH], c_uj[CH];
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = (k0 - i > 0) ? k0 - i : 0;
-                    c_ul[i] = SHARED ? T(0) : NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = tIV[k * IV_ROWS + 12 + j];
+                    c_ul[i] = NMPC_UL0( k * NU + j); c_uj[i] = tIV[k * IV_ROWS + 12 + j];
                 }
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = k0 - i;
@@ -1057,7 +1059,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int i = 0; i < CH; i++) {
                     const int k = (k0 - i > 0) ? k0 - i : 0;
                     const T *ivk = tIV + k * IV_ROWS;
-                    c_ul[i] = NMPC_TLD(w.ul, ULR, k * NU + j); c_uj[i] = ivk[12 + j]; c_pc[i] = ivk[16 + j];
+                    c_ul[i] = NMPC_UL0( k * NU + j); c_uj[i] = ivk[12 + j]; c_pc[i] = ivk[16 + j];
                     c_rk[i] = NMPC_TLD(w.qr, QRR, k * QR_ROWS + NX + j); c_qr[i] = NMPC_TLD(w.qr, QRR, k * QR_ROWS + rr);
                     c_xk[i] = tLM[k * TLM_ROWS + 66 + rr];
                 }
@@ -1126,7 +1128,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) nM[i] = lmn[rr * 4 + i];
             NMPC_UNROLL for (int i = 0; i < 10; i++) nLf[i] = lmn[52 + i];
-            n_ul = NMPC_TLD(w.ul, ULR, k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_ua = ivn[12 + j];
+            n_ul = NMPC_UL0( k * NU + j); n_uu = ivn[j]; n_l2 = ivn[4 + j]; n_l3 = ivn[8 + j]; n_ua = ivn[12 + j];
         };
         prefetch_bwd(N - 1);
         for (int k = N - 1; k >= 0; k--) {
@@ -1222,7 +1224,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         T ms = 0;
         for (int k = 0; k < N; k++) {
             T *ivk = tIV + k * IV_ROWS;
-            const T ul = NMPC_TLD(w.ul, ULR, k * NU + j);
+            const T ul = NMPC_UL0( k * NU + j);
             T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
             const T lo = lbj - ul, hi = ubj - ul;
             const Pair<T> pr(u, ll, lu, lo, hi);
@@ -1273,14 +1275,14 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (fast) {
             // the workspace iterate (xl, ul) is not read again after this kernel: the new iterate goes
             // straight to the caller's arrays (13- and 4-element runs per team), or nowhere but u0
-            u0_new = NMPC_TLD(w.ul, ULR, j) + tIV[uoff];
+            u0_new = NMPC_UL0( j) + tIV[uoff];
             if (out.x_out || out.u_out) {
                 for (int k0 = 0; k0 <= N; k0 += CH) {
                     T uv[CH], ulv[CH], xlv[CH], xhv[CH];
                     NMPC_UNROLL for (int i = 0; i < CH; i++) {
                         const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
                         uv[i] = tIV[ku * IV_ROWS + uoff];
-                        ulv[i] = NMPC_TLD(w.ul, ULR, ku * NU + j);
+                        ulv[i] = NMPC_UL0( ku * NU + j);
                         xlv[i] = NMPC_TLD(w.xl, XLR, k * NX + rr);
                         xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot
                     }
@@ -1302,7 +1304,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
                 const int k = (k0 + i < N) ? k0 + i : N - 1;
                 uv[i] = tIV[k * IV_ROWS + uoff];
-                ulv[i] = NMPC_TLD(w.ul, ULR, k * NU + j);
+                ulv[i] = NMPC_UL0( k * NU + j);
                 xlv[i] = NMPC_TLD(w.xl, XLR, (k + 1) * NX + rr);
             }
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -1619,7 +1621,7 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     if (valid && cmpl) {
         NMPC_UNROLL for (int i = 0; i < HC; i++) {
             if (i < N) {
-                NMPC_TST(w.ul, ULR, i * NU + j, hu[i]);
+                if (!c.shared) NMPC_TST(w.ul, ULR, i * NU + j, hu[i]);     // shared cold start: u_k = 0, folded in team_ipm
                 NMPC_TST(w.qr, QRR, i * QR_ROWS + NX + j, Wrj * (hu[i] - hyu[i]));
             }
         }
@@ -1641,7 +1643,7 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
                     NMPC_TST(w.qr, QRR, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
                 }
                 if (cmpl) {
-                    NMPC_TST(w.ul, ULR, k * NU + j, uv[i]);
+                    if (!c.shared) NMPC_TST(w.ul, ULR, k * NU + j, uv[i]);
                     NMPC_TST(w.qr, QRR, k * QR_ROWS + NX + j, Wrj * (uv[i] - yu[i]));
                 }
             }
