@@ -1283,7 +1283,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
                         uv[i] = tIV[ku * IV_ROWS + uoff];
                         ulv[i] = NMPC_UL0( ku * NU + j);
-                        xlv[i] = NMPC_TLD(w.xl, XLR, k * NX + rr);
+                        xlv[i] = NMPC_TLD(w.xl, XLR, (SHARED ? 0 : k) * NX + rr);        // shared cold start: x_k = x0, staged once
                         xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot
                     }
                     NMPC_UNROLL for (int i = 0; i < CH; i++) {
@@ -1305,7 +1305,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 const int k = (k0 + i < N) ? k0 + i : N - 1;
                 uv[i] = tIV[k * IV_ROWS + uoff];
                 ulv[i] = NMPC_UL0( k * NU + j);
-                xlv[i] = NMPC_TLD(w.xl, XLR, (k + 1) * NX + rr);
+                xlv[i] = NMPC_TLD(w.xl, XLR, (SHARED ? 0 : k + 1) * NX + rr);
             }
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
                 const int k = k0 + i;
@@ -1613,7 +1613,7 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     if (valid && rowl) {              // two exec-mask regions for all stages (stage bound: scalar branch)
         NMPC_UNROLL for (int i = 0; i < HC; i++) {
             if (i < N) {
-                NMPC_TST(w.xl, XLR, i * NX + rr, hx[i]);
+                if (!c.shared || i == 0) NMPC_TST(w.xl, XLR, i * NX + rr, hx[i]);    // shared cold start: stage 0 stands for all
                 NMPC_TST(w.qr, QRR, i * QR_ROWS + rr, Wqr * (hx[i] - hyx[i]));
             }
         }
@@ -1639,7 +1639,7 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
             const int k = k0 + i;
             if (k < N && valid) {
                 if (rowl) {
-                    NMPC_TST(w.xl, XLR, k * NX + rr, xv[i]);
+                    if (!c.shared) NMPC_TST(w.xl, XLR, k * NX + rr, xv[i]);
                     NMPC_TST(w.qr, QRR, k * QR_ROWS + rr, Wqr * (xv[i] - yx[i]));
                 }
                 if (cmpl) {
@@ -1650,7 +1650,7 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
         }
     }
     if (rowl && valid) {
-        NMPC_TST(w.xl, XLR, N * NX + rr, xN);
+        if (!c.shared) NMPC_TST(w.xl, XLR, N * NX + rr, xN);
         NMPC_TST(w.qr, QRR, N * QR_ROWS + rr, WqNr * (xN - yeN));
     }
 }
