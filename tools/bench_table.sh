@@ -8,7 +8,7 @@ d = json.load(open("gpurun_out/bench_q.json"))
 r = d["roofline"]
 print(f"[{sys.argv[1]:44s}] {d['value']/1e6:9.4f} M/s  step {d['ms_per_step']:.4f} ms  kernel {r['kernel_ms']:.4f}  "
       f"ipm {d['ipm_iterations']['mean']:.2f}/{d['ipm_iterations']['max']}  pol {d['active_set_passes']['mean']:.3f}/{d['active_set_passes']['max']}  "
-      f"alu {r['alu']['frac']:.4f} hbm {r['hbm']['frac']:.5f}  st {d['status_histogram']}")
+      f"flop-frac exec {r['alu']['frac']:.4f} nominal {r['alu']['nominal']['frac']:.4f} hbm {r['hbm']['frac']:.5f}  st {d['status_histogram']}")
 PY
 }
 row
