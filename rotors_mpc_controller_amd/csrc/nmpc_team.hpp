@@ -280,7 +280,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     };
 
     if (SHARED) {
-        if (lds_prefilled) rows_from_lds();     // the fused preparation left the stage matrices in LDS
+        if (lds_prefilled) { if (!MF) rows_from_lds(); }   // the fused preparation left the stage matrices in LDS
+                                                          // (the tile path re-reads its rows where it needs them)
         else load_stage(0);
     }
 
