@@ -146,14 +146,23 @@ def test_single_instance_set_solve_get_surface():
 
 
 def test_long_horizon_and_odd_sizes():
-    for N, B in ((3, 5), (60, 33)):
+    """Horizons 1 and 2 (no checkpoint window, hoisted stage loops longer than the horizon), a few stages,
+    a long horizon; batches that leave teams of the last wave idle; cold start, then a warm-started
+    second iteration (per-stage linearisation)."""
+    for N, B in ((1, 3), (2, 4), (3, 5), (60, 33)):
         s = make_solver(N=N, max_batch=64)
         c = oracle_cfg(polish=True, N=N)
         yref, ye = hover(s.config)
         x0 = sample_x0(B, N, **AGGRESSIVE)
-        out = s.solve_batch(x0, yref, ye)
-        ref = O.solve_batch(c, x0, yref, ye)
+        out = s.solve_batch(x0, yref, ye, want_traj=True)
+        ref = O.solve_batch(c, x0, yref, ye, want_traj=True)
+        assert np.array_equal(out["status"], ref["status"])
         np.testing.assert_allclose(out["u0"], ref["u0"], atol=TOL_U)
+        np.testing.assert_allclose(out["x"], ref["x"], atol=TOL_X)
+        x1 = x0 + np.random.default_rng(N).normal(0, 0.01, x0.shape)
+        o2 = s.solve_batch(x1, yref, ye, x_init=out["x"], u_init=out["u"])
+        r2 = O.solve_batch(c, x1, yref, ye, x_init=out["x"], u_init=out["u"])
+        np.testing.assert_allclose(o2["u0"], r2["u0"], atol=TOL_U)
 
 
 def test_full_size_properties_batch_4096():
