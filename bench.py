@@ -246,9 +246,6 @@ def main() -> None:
         alu_tf = flops * B / kern_s / 1e12
         flops_x = executed_flops(N, n_ipm, st["polish_mean"], not args.no_share)
         alu_x_tf = flops_x * B / kern_s / 1e12
-        # streamed solver workspace per solve (kernel table): rows read+written per stage and IPM iteration
-        ws_rows = 820 if args.no_share else 420
-        ws_gbs = (n_kkt * N * ws_rows * esz) * B / kern_s / 1e9
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of the SAME command
         # (tools/rocprof_capture.sh); FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per the
         # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
@@ -261,7 +258,8 @@ def main() -> None:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
         kernel_name = "k_team_ipm" if args.mapping == "team" else "k_ipm"
         hbm = dict(achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS,
-                   algorithmic_bytes_per_solve=alg_b, workspace_model_gbs=ws_gbs)
+                   algorithmic_bytes_per_solve=alg_b,
+                   measured_traffic_gbs=(traffic / kern_s / 1e9 if traffic is not None else None))
         # flops: `executed` prices what the path really does per solve (executed_flops above); `nominal` is the
         # dense-equivalent count of SURVEY 8d with every KKT round priced as a full IPM iteration and N
         # linearisations - kept for comparison, it over-counts the default path by ~1.9x
