@@ -714,11 +714,6 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                 }
                 l_solve(Lf, mv);
-                // the natural-layout copies of L, m (and M below) feed the interior-point sweeps D/E only
-                if (any_ipm && r == 0 && st_ok) {
-                    NMPC_UNROLL for (int i = 0; i < 10; i++) lmk[52 + i] = Lf[i];
-                    NMPC_UNROLL for (int i = 0; i < NU; i++) lmk[62 + i] = mv[i];
-                }
                 // Y = L^-T as a tile (lane (a,c) holds (L^-1 e_a)_c), M = L^-1 X = Y' X
                 T ea[NU];
                 NMPC_UNROLL for (int i = 0; i < NU; i++) ea[i] = (i == ta) ? T(1) : T(0);
@@ -727,7 +722,6 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T M[4];
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     M[jt] = mfma44(Y, X[jt], T(0));
-                    if (any_ipm && st_ok && natC[jt] >= 0) lmk[natC[jt] * 4 + ta] = M[jt];
                     // for the forward sweep: the same tile where the lane that needs it TRANSPOSED will read it
                     if (st_ok) lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
                 }
@@ -1121,10 +1115,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (__ballot(ipm2) == 0) continue;   // nobody in this wave is iterating the interior point method
 
         // ================= sweep D: backward homogeneous solve
-        if (SHARED && MF) rows_from_lds();
+        T n_ua = 0;
+        if constexpr (!MF) {
         pv = 0;
         p = 0;
-        T n_ua;
         auto prefetch_bwd = [&](int k) {
             const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
             NMPC_UNROLL for (int i = 0; i < NU; i++) nM[i] = lmn[rr * 4 + i];
@@ -1167,6 +1161,69 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
+        } else {
+            // ---- tile form (FP64): the costate of the correction is four column tiles; g = dr + B'pi, m = L^-1 g,
+            // pi_k = Abar'pi - Mbar'm are 17 v_mfma_f64_4x4x4 per stage on the tiles the factor sweep left
+            const int ta = r >> 2, tc = r & 3;
+            int natR[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) natR[t] = nat_of(t, ta);
+            const T lb_a = sel4(c.lbu, ta), ub_a = sel4(c.ubu, ta);
+            T Aq0[4], Aq1z[4], Bt[4];
+            auto load_tiles = [&]() {          // as in the factor sweep, without b and the homogeneous 1
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    const int l = natR[kt] >= 0 ? natR[kt] : 0;
+                    const bool real = natR[kt] >= 0;
+                    const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc];
+                    Aq0[kt] = real ? a0 : T(0);
+                    Aq1z[kt] = (real && tc < 3) ? a1 : T(0);
+                    Bt[kt] = real ? bb : T(0);
+                }
+            };
+            if (SHARED) load_tiles(); else fetch_stage(N - 1);
+            T pit[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) pit[t] = 0;
+            constexpr int CHD = 5;
+            for (int k0 = N - 1; k0 >= 0; k0 -= CHD) {
+                T cMn[CHD][4], cY[CHD], c_ul[CHD], c_u[CHD], c_ll[CHD], c_lu[CHD], c_ua[CHD];
+                NMPC_UNROLL for (int i = 0; i < CHD; i++) {
+                    const int k = (k0 - i > 0) ? k0 - i : 0;
+                    const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMn[i][jt] = lmn[TLM_MT + jt * 16 + tc * 4 + ta];   // Mbar[a][4jt+c]
+                    cY[i] = lmn[TLM_Z + tc * 4 + ta];                                                            // (L^-1)[c][a]
+                    c_ul[i] = NMPC_UL0(k * NU + ta); c_u[i] = ivn[ta]; c_ll[i] = ivn[4 + ta]; c_lu[i] = ivn[8 + ta]; c_ua[i] = ivn[12 + ta];
+                }
+                NMPC_UNROLL for (int i = 0; i < CHD; i++) {
+                    const int k = k0 - i;
+                    if (k >= 0) {
+                        if (!SHARED) { put_stage(); if (k > 0) fetch_stage(k - 1); load_tiles(); }
+                        T *lmk = tLM + k * TLM_ROWS;
+                        T drt;
+                        {
+                            const T u = c_u[i], ll = c_ll[i], lu = c_lu[i];
+                            const Pair<T> pr(u, ll, lu, lb_a - c_ul[i], ub_a - c_ul[i]);
+                            const T da = c_ua[i] - u;
+                            const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                            const T cl = dla * da, cu = -dua * da;
+                            drt = tc == 0 ? -(sigmu - cl) * pr.itl + (sigmu - cu) * pr.itu : T(0);
+                        }
+                        const T g = mfma44(Bt[2], pit[2], mfma44(Bt[0], pit[0], drt)) + mfma44(Bt[3], pit[3], mfma44(Bt[1], pit[1], T(0)));
+                        const T mvt = mfma44(cY[i], g, T(0));                     // lane (a,0): m_a
+                        if (tc == 0 && ipm2 && valid) lmk[TLM_MT + 60 + ta] = mvt;  // column 15 of Mbar, where sweep E reads it
+                        if (k > 0) {
+                            T an[4];
+                            an[0] = pit[0];
+                            an[1] = dt_v * pit[0] + pit[1];
+                            an[2] = mfma44(Aq0[2], pit[2], mfma44(Aq0[0], pit[0], T(0))) + mfma44(Aq0[3], pit[3], mfma44(Aq0[1], pit[1], T(0)));
+                            an[3] = mfma44(Aq1z[2], pit[2], mfma44(Aq1z[0], pit[0], T(0))) + mfma44(Aq1z[3], pit[3], mfma44(Aq1z[1], pit[1], T(0)));
+                            NMPC_UNROLL for (int t = 0; t < 4; t++) {
+                                const T v = an[t] - mfma44(cMn[i][t], mvt, T(0));
+                                pit[t] = (tc == 0 && natR[t] >= 0) ? v : T(0);
+                            }
+                        }
+                    }
+                }
+            }
+        }
         NMPC_STAMP(2)
         __syncthreads();   // m of every stage (written by lane 0) visible to the team
 
@@ -1174,6 +1231,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         xh = 0;
         p = 0;
         rmax = c.tau;      // alpha = min(1, tau / max inverse step) = tau / max(rmax, tau)
+        if constexpr (!MF) {
         auto prefetch_fwd2 = [&](int k) {
             prefetch_fwd(k);
             n_ua = tIV[k * IV_ROWS + 12 + j];
@@ -1216,8 +1274,72 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
             p ^= 1;
         }
-        NMPC_STAMP(3)
         if (cmpl) sRed[12 + j] = rmax;
+        } else {
+            // ---- tile form (FP64): as sweep B, homogeneous dynamics (no b), m from sweep D in column 15 of Mbar
+            const int ta = r >> 2, tc = r & 3;
+            int natC[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) natC[t] = nat_of(t, tc);
+            const T lb_a = sel4(c.lbu, ta), ub_a = sel4(c.ubu, ta);
+            T AT2[4], AT3z[4], BT[4];
+            auto load_tiles_T = [&]() {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    const int l = natC[it] >= 0 ? natC[it] : 0;
+                    const bool real = natC[it] >= 0;
+                    const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta];
+                    AT2[it] = real ? a2 : T(0);
+                    AT3z[it] = (real && ta < 3) ? a3 : T(0);
+                    BT[it] = real ? bb : T(0);
+                }
+            };
+            if (SHARED) load_tiles_T(); else fetch_stage(0);
+            T xt[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = 0;
+            const T one15 = (ta == 3 && tc == 0) ? T(1) : T(0);        // homogeneous coordinate, for the m term only
+            constexpr int CHE = 5;
+            for (int k0 = 0; k0 < N; k0 += CHE) {
+                T cMT[CHE][4], cZ[CHE], c_ul[CHE], c_u[CHE], c_ll[CHE], c_lu[CHE], c_ua[CHE];
+                NMPC_UNROLL for (int i = 0; i < CHE; i++) {
+                    const int k = (k0 + i < N) ? k0 + i : N - 1;
+                    const T *lmn = tLM + k * TLM_ROWS, *ivn = tIV + k * IV_ROWS;
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cMT[i][jt] = lmn[TLM_MT + jt * 16 + r];
+                    cZ[i] = lmn[TLM_Z + r];
+                    c_ul[i] = NMPC_UL0(k * NU + ta); c_u[i] = ivn[ta]; c_ll[i] = ivn[4 + ta]; c_lu[i] = ivn[8 + ta]; c_ua[i] = ivn[12 + ta];
+                }
+                NMPC_UNROLL for (int i = 0; i < CHE; i++) {
+                    const int k = k0 + i;
+                    if (k < N) {
+                        if (!SHARED) { put_stage(); if (k + 1 < N) fetch_stage(k + 1); load_tiles_T(); }
+                        T *ivk = tIV + k * IV_ROWS;
+                        T xn[4];
+                        xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3z[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                        const T v = mfma44(cMT[i][2], xt[2], mfma44(cMT[i][0], xt[0], T(0)))
+                                  + mfma44(cMT[i][3], xt[3] + one15, mfma44(cMT[i][1], xt[1], T(0)));
+                        const T ut = -mfma44(cZ[i], v, T(0));
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+                        {
+                            const T u = c_u[i], ll = c_ll[i], lu = c_lu[i], ua = c_ua[i], ul = c_ul[i];
+                            const Pair<T> pr(u, ll, lu, lb_a - ul, ub_a - ul);
+                            const T da = ua - u;
+                            const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                            const T cl = dla * da, cu = -dua * da;
+                            const T d = da + ut;
+                            if (tc == 0 && ipm2 && valid) ivk[16 + ta] = d;
+                            const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                            const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                            if (tc == 0) {
+                                rmax = fmax(rmax, fmax(-d * pr.itl, d * pr.itu));
+                                rmax = fmax(rmax, fmax(-dl * fast_rcp(ll), -du * fast_rcp(lu)));
+                            }
+                        }
+                        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
+                    }
+                }
+            }
+            if (tc == 0) sRed[12 + ta] = rmax;
+        }
+        NMPC_STAMP(3)
         __syncthreads();
         rmax = fmax(fmax(sRed[12], sRed[13]), fmax(sRed[14], sRed[15]));
         const T alpha = c.tau / rmax;

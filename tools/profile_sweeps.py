@@ -29,11 +29,14 @@ ap.add_argument("--dtype", default="f64")
 ap.add_argument("--no-share", action="store_true")
 ap.add_argument("--mapping", default="team")
 ap.add_argument("--dist", default="near_hover")
+ap.add_argument("--no-polish", action="store_true")
 a = ap.parse_args()
 
 B = a.batch
 cfg = _lib.default_config(max_batch=B, dtype=_lib.DTYPE_F64 if a.dtype == "f64" else _lib.DTYPE_F32,
                           flags=(0 if a.no_share else 1) | (2 if a.mapping == 'team' else 0))
+if a.no_polish:
+    cfg.update(qp_polish=0)
 if a.dtype == "f32":
     cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
 s = NmpcOcpSolver(cfg)
