@@ -1345,24 +1345,36 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         const T alpha = c.tau / rmax;
         // ================= sweep F: primal-dual update, duality measure of the new iterate
         T ms = 0;
-        for (int k = 0; k < N; k++) {
-            T *ivk = tIV + k * IV_ROWS;
-            const T ul = NMPC_UL0( k * NU + j);
-            T u = ivk[j], ll = ivk[4 + j], lu = ivk[8 + j];
-            const T lo = lbj - ul, hi = ubj - ul;
-            const Pair<T> pr(u, ll, lu, lo, hi);
-            const T da = ivk[12 + j] - u, d = ivk[16 + j];
-            const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
-            const T cl = dla * da, cu = -dua * da;
-            const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
-            const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
-            u += alpha * d; ll += alpha * dl; lu += alpha * du;
-            if (cmpl && ipm2 && valid) {
-                ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu;
-                // active-set guess for a later polish attempt: a bound whose multiplier exceeds its slack
-                ivk[16 + j] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
+        constexpr int CHF = 10;           // iterate and directions are fetched a chunk of stages at a time (see sweep C)
+        for (int k0 = 0; k0 < N; k0 += CHF) {
+            T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_ua[CHF], f_d[CHF];
+            NMPC_UNROLL for (int i = 0; i < CHF; i++) {
+                const int k = (k0 + i < N) ? k0 + i : N - 1;
+                const T *ivn = tIV + k * IV_ROWS;
+                f_ul[i] = NMPC_UL0(k * NU + j);
+                f_u[i] = ivn[j]; f_ll[i] = ivn[4 + j]; f_lu[i] = ivn[8 + j]; f_ua[i] = ivn[12 + j]; f_d[i] = ivn[16 + j];
             }
-            ms += ll * (u - lo) + lu * (hi - u);
+            NMPC_UNROLL for (int i = 0; i < CHF; i++) {
+                const int k = k0 + i;
+                if (k < N) {
+                    T *ivk = tIV + k * IV_ROWS;
+                    T u = f_u[i], ll = f_ll[i], lu = f_lu[i];
+                    const T lo = lbj - f_ul[i], hi = ubj - f_ul[i];
+                    const Pair<T> pr(u, ll, lu, lo, hi);
+                    const T da = f_ua[i] - u, d = f_d[i];
+                    const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                    const T cl = dla * da, cu = -dua * da;
+                    const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                    const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
+                    if (cmpl && ipm2 && valid) {
+                        ivk[j] = u; ivk[4 + j] = ll; ivk[8 + j] = lu;
+                        // active-set guess for a later polish attempt: a bound whose multiplier exceeds its slack
+                        ivk[16 + j] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
+                    }
+                    ms += ll * (u - lo) + lu * (hi - u);
+                }
+            }
         }
         NMPC_STAMP(4)
         if (cmpl) sRed[16 + j] = ms;
