@@ -89,9 +89,10 @@ typedef struct nmpc_config {
     int32_t qp_polish_passes;  /* active-set corrections per attempt */
     int32_t qp_polish_budget;  /* no new attempt after this many passes */
     double qp_polish_mu;       /* first attempt when mu <= this (>= mu0: before any IPM iteration), then every 100x below */
-    int32_t qp_polish_ckpt;    /* leading stages whose Riccati state (P_k, p_k) an active-set pass checkpoints: the next
-                                  pass refactorises only stages <= the highest stage whose pin set changed when that
-                                  lies inside this window, else the whole horizon.  0 = always the whole horizon      */
+    int32_t qp_polish_ckpt;    /* leading stages whose Riccati state (P_k, p_k) a corrected active-set pass checkpoints
+                                  (the first pass of an attempt keeps at most two): the next pass refactorises only
+                                  stages <= the highest stage whose pin set changed when a current checkpoint
+                                  covers it, else the whole horizon.  0 = always the whole horizon                     */
     int32_t reserved_;
 } nmpc_config;
 
@@ -100,8 +101,8 @@ typedef struct nmpc_stats {
     int32_t iter_min, iter_max;/* IPM iterations over the batch */
     double iter_mean;
     int32_t n_status[5];       /* histogram of the acados status codes */
-    double ms_prepare;         /* device time of the linearisation kernel (HIP events) */
-    double ms_solve;           /* device time of the IPM kernel */
+    double ms_prepare;         /* device time of the linearisation kernel (HIP events); 0 when it is fused into the solve */
+    double ms_solve;           /* device time of the solve kernel; both 0 after nmpc_set_timing(s, 0) */
     uint64_t workspace_bytes;
     double polish_mean;        /* active-set passes per instance (team mapping), mean / max */
     int32_t polish_max;
