@@ -363,6 +363,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 vmin = vt < vmin ? vt : vmin;
             }
             if (ks >= vmin) ks = N - 1;
+            ks = __builtin_amdgcn_readfirstlane(ks);      // the same in every lane: make the sweep a scalar loop
         }
 
         // Checkpoint window of this pass: the first pass of an attempt keeps only the first two stages (almost
