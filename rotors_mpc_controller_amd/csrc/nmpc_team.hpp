@@ -874,6 +874,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
             // the tile path has no costate sweep: xhat is only read back when the caller wants the state trajectory
             const bool want_xhat = out.x_out != nullptr;
+            const bool want_u = out.u_out != nullptr || out.x_out != nullptr || any_ipm;
             int kchgB = -1;           // highest stage whose pin set this pass changes
             const bool wave_pins = __ballot(pol2 && maybe_pins) != 0;
             int xslot[4];
@@ -945,7 +946,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                                 npc = uj < lo - tolb ? T(-1) : (uj > hi + tolb ? T(1) : T(0));
                             }
                             if (tc == 0) {
-                                if (st_ok2) { ivk[12 + ta] = ue; if (pol2 && npc != pc) ivk[16 + ta] = npc; }
+                                // candidate inputs: all stages for the interior-point sweeps and a requested input
+                                // trajectory, stage 0 (the command u0) otherwise
+                                if (st_ok2) { if (k == 0 || want_u) ivk[12 + ta] = ue; if (pol2 && npc != pc) ivk[16 + ta] = npc; }
                                 dirty += nanq ? HEAVY : ((npc != pc) ? T(1) : T(0));
                                 kchgB = (npc != pc) ? k : kchgB;                  // ascending k: the last one is the highest
                             }
