@@ -18,11 +18,12 @@ from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_re
 
 WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8192
+POLISH = 0 if "--no-polish" in sys.argv else 1        # --no-polish: the plain interior-point path on both sides
 worst = 0.0
 bad = 0
 for share in (1, 0):
-    s = NmpcOcpSolver(_lib.default_config(max_batch=B, flags=share | _lib.FLAG_TEAM_MAPPING))
-    c = O.default_config(qp_gamma=0.0, qp_polish=1)
+    s = NmpcOcpSolver(_lib.default_config(max_batch=B, flags=share | _lib.FLAG_TEAM_MAPPING, qp_polish=POLISH))
+    c = O.default_config(qp_gamma=0.0, qp_polish=POLISH)
     yref, ye = hover_reference(s.config.N, s.config.mass * s.config.gravity / 4.0)
     for name, dist in (("near", NEAR_HOVER), ("aggr", AGGRESSIVE), ("wild", WILD)):
         for seed in (11, 12, 13):
