@@ -189,6 +189,14 @@ int nmpc_commands_to_motor_speeds_device(nmpc_solver *s, int B, const void *u, d
                                          double motor_min_speed, double motor_max_speed, void *speeds,
                                          void *clipped, void *hip_stream);
 
+/* replaces the command hand-over of MPCControllerNode._loop (nodes/mpc_controller_node:122-131): where
+ * status [B] is 0 the command u0 [B][4], clipped to the input bounds (:153-154), becomes the held command
+ * (_last_command, :164); elsewhere the previous held command stays (re-published, :126-127).
+ * held [B][4] is read and written; the caller initialises it (the node has no command before its first
+ * successful solve).                                                                                   */
+int nmpc_hold_command_device(nmpc_solver *s, int B, const void *u0, const int32_t *status, void *held,
+                             void *hip_stream);
+
 /* plant step of a closed-loop rollout: x [B][13], u [B][4] -> x_next [B][13] with the
  * controller's own model and ERK scheme (controller.py:183-188,267-355) over one interval dt;
  * normalize_q != 0 renormalises the quaternion as controller.py:406-409 does on every tick          */

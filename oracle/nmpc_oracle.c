@@ -1026,6 +1026,10 @@ int orc_solve_batch(const orc_config *c, int Bn, const double *x0, const double 
         if (status) status[ib] = s;
         if (iters) iters[ib] = st.qp_iter;
         for (int i = 0; i < NU; i++) u0[(size_t)ib * NU + i] = (s == 0) ? ut[i] : 0.0; /* controller.py:448-450 */
+        if (s != 0) { /* the warm start is invalidated (controller.py:448-450): hand back the cold-start point (:425-431) */
+            for (int k = 0; k <= N; k++) memcpy(xt + (size_t)k * NX, x0i, sizeof(double) * NX);
+            memset(ut, 0, sizeof(double) * (size_t)N * NU);
+        }
         if (x_out) memcpy(x_out + (size_t)ib * (N + 1) * NX, xt, sizeof(double) * (size_t)(N + 1) * NX);
         if (u_out) memcpy(u_out + (size_t)ib * N * NU, ut, sizeof(double) * (size_t)N * NU);
         free(xt);

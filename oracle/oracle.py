@@ -43,10 +43,13 @@ class OrcStats(C.Structure):
 
 
 def build(force: bool = False) -> Path:
-    so = _HERE / "libnmpc_oracle.so"
+    # NMPC_SANITIZE=1: the AddressSanitizer + UBSan build (the process must have libasan preloaded,
+    # tools/run_sanitized_tests.sh)
+    san = os.environ.get("NMPC_SANITIZE") == "1"
+    so = _HERE / ("libnmpc_oracle_asan.so" if san else "libnmpc_oracle.so")
     src = _HERE / "nmpc_oracle.c"
     if force or not so.exists() or so.stat().st_mtime < src.stat().st_mtime:
-        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s"],
+        subprocess.check_call(["make", "-C", str(_HERE), "-B" if force else "-s"] + (["asan"] if san else []),
                               stdout=subprocess.DEVNULL)
     return so
 

@@ -87,6 +87,22 @@ __global__ void k_motor_speeds(int n /*B*4*/, const T *__restrict__ u, Bounds4<T
     if (clipped) clipped[i] = c;
 }
 
+// What MPCControllerNode._loop does with a solve result (nodes/mpc_controller_node:122-131,152-164): a
+// successful solve publishes its command clipped to the input bounds and remembers it as _last_command; a
+// failed one (status != 0) re-publishes _last_command.  held [B][4] is that memory and, after the call,
+// the command the plant receives.
+template <class T>
+__global__ void k_hold_command(int n /*B*4*/, const T *__restrict__ u0, const int32_t *__restrict__ status, Bounds4<T> bd,
+                               T *__restrict__ held)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int j = i & 3;
+    const T lbu = j == 0 ? bd.lb[0] : (j == 1 ? bd.lb[1] : (j == 2 ? bd.lb[2] : bd.lb[3]));
+    const T ubu = j == 0 ? bd.ub[0] : (j == 1 ? bd.ub[1] : (j == 2 ? bd.ub[2] : bd.ub[3]));
+    if (status[i >> 2] == 0) held[i] = fmin(fmax(u0[i], lbu), ubu);
+}
+
 // The plant of a closed-loop Monte-Carlo rollout: the same model and the same ERK scheme
 // as the controller's prediction (controller.py:183-188, 267-355), one shooting interval, states only.
 // normalize_q mirrors what PositionNMPC.solve does to every measured state (controller.py:406-409).

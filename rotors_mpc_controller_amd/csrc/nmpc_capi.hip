@@ -98,7 +98,7 @@ struct nmpc_solver {
     bool timing = true;   // nmpc_set_timing: HIP events around the kernels of every solve
     // single-instance slot (AcadosOcpSolver.set/get state)
     std::vector<double> sx, su, syref, syref_e, sx0;
-    int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2|4 picks the register budget variant
+    int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
     int team_mfma = 1;  // FP64 factor sweep in tile form on v_mfma_f64_4x4x4; NMPC_TEAM_MFMA=0 keeps the VALU form
@@ -402,6 +402,7 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
 static int ensure_staging(nmpc_solver *s, size_t B)
 {
     if (B <= s->staged_batch) return 0;
+    s->staged_batch = 0;      // a failed grow below must force a fresh allocation on the next call
     void **ps[] = {&s->s_x0, &s->s_yref, &s->s_yref_e, &s->s_xi, &s->s_ui, &s->s_u0, &s->s_xo, &s->s_uo};
     for (void **p : ps)
         if (*p) { (void)hipFree(*p); *p = nullptr; }
@@ -604,6 +605,27 @@ int nmpc_commands_to_motor_speeds_device(nmpc_solver *s, int B, const void *u, d
         for (int i = 0; i < 4; i++) { bd.lb[i] = (float)s->cfg.lbu[i]; bd.ub[i] = (float)s->cfg.ubu[i]; }
         hipLaunchKernelGGL(k_motor_speeds<float>, grid, block, 0, st, n, (const float *)u, bd, (float)kf, (float)w_min,
                            (float)w_max, (float *)speeds, (float *)clipped);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+int nmpc_hold_command_device(nmpc_solver *s, int B, const void *u0, const int32_t *status, void *held, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !u0 || !status || !held) return s->fail(NMPC_EARG, "hold_command: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int n = B * NU;
+    const dim3 grid((n + 255) / 256), block(256);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Bounds4<double> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = s->cfg.lbu[i]; bd.ub[i] = s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_hold_command<double>, grid, block, 0, st, n, (const double *)u0, status, bd, (double *)held);
+    } else {
+        Bounds4<float> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = (float)s->cfg.lbu[i]; bd.ub[i] = (float)s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_hold_command<float>, grid, block, 0, st, n, (const float *)u0, status, bd, (float *)held);
     }
     HIP_TRY(s, hipGetLastError());
     return 0;

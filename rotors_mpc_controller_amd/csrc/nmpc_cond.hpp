@@ -459,12 +459,13 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
     w.status[lane] = nlp_status;
     if (out.status) out.status[lane] = nlp_status;
     for (int i = 0; i < NU; i++) out.u0[(size_t)lane * NU + i] = nlp_status == 0 ? NMPC_LD(w.ul, i) : T(0);
+    const bool failed = nlp_status != 0;   // hand back the cold-start point, as lane_ipm does
     if (out.x_out)
         for (int k = 0; k <= N; k++)
-            for (int i = 0; i < NX; i++) out.x_out[((size_t)lane * (N + 1) + k) * NX + i] = NMPC_LD(w.xl, k * NX + i);
+            for (int i = 0; i < NX; i++) out.x_out[((size_t)lane * (N + 1) + k) * NX + i] = NMPC_LD(w.xl, (failed ? 0 : k) * NX + i);
     if (out.u_out)
         for (int k = 0; k < N; k++)
-            for (int i = 0; i < NU; i++) out.u_out[((size_t)lane * N + k) * NU + i] = NMPC_LD(w.ul, k * NU + i);
+            for (int i = 0; i < NU; i++) out.u_out[((size_t)lane * N + k) * NU + i] = failed ? T(0) : NMPC_LD(w.ul, k * NU + i);
 }
 
 }  // namespace nmpc

@@ -312,16 +312,19 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
     if (out.status) out.status[lane] = nlp_status;
     NMPC_UNROLL for (int i = 0; i < NU; i++)
         out.u0[(size_t)lane * NU + i] = nlp_status == 0 ? NMPC_LD(w.ul, i) : T(0);   // controller.py:448-452
+    // a failed instance hands back the cold-start point (x_k = x0, u_k = 0): fed back as a warm start it
+    // restarts cold, as the reference does after a failure (controller.py:425-431, 448-450)
+    const bool failed = nlp_status != 0;
     if (out.x_out) {
         for (int k = 0; k <= N; k++) {
             NMPC_UNROLL for (int i = 0; i < NX; i++)
-                out.x_out[((size_t)lane * (N + 1) + k) * NX + i] = NMPC_LD(w.xl, k * NX + i);
+                out.x_out[((size_t)lane * (N + 1) + k) * NX + i] = NMPC_LD(w.xl, (failed ? 0 : k) * NX + i);
         }
     }
     if (out.u_out) {
         for (int k = 0; k < N; k++) {
             NMPC_UNROLL for (int i = 0; i < NU; i++)
-                out.u_out[((size_t)lane * N + k) * NU + i] = NMPC_LD(w.ul, k * NU + i);
+                out.u_out[((size_t)lane * N + k) * NU + i] = failed ? T(0) : NMPC_LD(w.ul, k * NU + i);
         }
     }
 }

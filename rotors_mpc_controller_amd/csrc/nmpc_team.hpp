@@ -1489,11 +1489,18 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         if (r == 0) { w.iters[inst] = it; w.status[inst] = nlp_status; if (w.npol) w.npol[inst] = from_ua ? npol : -npol; }   // > 0: accepted active-set solution
         if (cmpl) out.u0[(size_t)inst * NU + j] = nlp_status == 0 ? u0_new : T(0);   // controller.py:448-452
         if (outputs_done) return;
+        // A failed instance (status 1 / 4) hands back the cold-start point (x_k = x0, u_k = 0,
+        // controller.py:425-431) instead of its - possibly poisoned, and under the shared cold start never
+        // staged - linearisation point: a caller that feeds x_out / u_out back as the next warm start then
+        // restarts cold, which is what the reference does after a failure (controller.py:448-450).
+        const bool failed = nlp_status != 0;
+        const T x0r = NMPC_TLD(w.xl, XLR, rr);                 // stage 0 is pinned to x0 in every variant
         if (out.x_out && rowl) {
-            for (int k = 0; k <= N; k++) out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = NMPC_TLD(w.xl, XLR, k * NX + rr);
+            for (int k = 0; k <= N; k++)
+                out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = failed ? x0r : NMPC_TLD(w.xl, XLR, k * NX + rr);
         }
         if (out.u_out && cmpl) {
-            for (int k = 0; k < N; k++) out.u_out[((size_t)inst * N + k) * NU + j] = NMPC_TLD(w.ul, ULR, k * NU + j);
+            for (int k = 0; k < N; k++) out.u_out[((size_t)inst * N + k) * NU + j] = failed ? T(0) : NMPC_TLD(w.ul, ULR, k * NU + j);
         }
     }
 }

@@ -30,6 +30,7 @@ class ClosedLoopRollout:
         self.yref, self.yref_e = z(B, N, 17), z(B, 13)
         self.pos, self.yaw = z(B, 3), z(B)
         self.hover = cfg.mass * cfg.gravity / 4.0
+        self.held = z(B, 4)       # the command the plant flies (the node's _last_command); starts at hover thrust
 
     def _tick(self, t: int, stream: int, warm: bool) -> None:
         """One control tick on `stream`: solve (warm-started from the other trajectory buffer), plant step."""
@@ -40,7 +41,11 @@ class ClosedLoopRollout:
                              x_init_ptr=self.xt[prev].data_ptr() if warm else 0,
                              u_init_ptr=self.ut[prev].data_ptr() if warm else 0,
                              x_out_ptr=self.xt[cur].data_ptr(), u_out_ptr=self.ut[cur].data_ptr(), stream=stream)
-        s.plant_step_device(B, self.x.data_ptr(), self.u0.data_ptr(), self.xn.data_ptr(), True, stream)
+        # a failed solve returns zeros (controller.py:448-450) and the node keeps flying its last command
+        # (nodes/mpc_controller_node:124-129); the solver has handed back the cold-start point for such an
+        # instance, so its next tick restarts cold although the launch is a warm-started one
+        s.hold_command_device(B, self.u0.data_ptr(), self.status.data_ptr(), self.held.data_ptr(), stream)
+        s.plant_step_device(B, self.x.data_ptr(), self.held.data_ptr(), self.xn.data_ptr(), True, stream)
         self.x.copy_(self.xn)                   # fixed buffers: the tick can be replayed from a HIP graph
 
     def run(self, x0: np.ndarray, steps: int, setpoint=(0.0, 0.0, 1.0), yaw: float = 0.0, log: bool = True,
@@ -54,6 +59,7 @@ class ClosedLoopRollout:
         self.x.copy_(torch.as_tensor(np.ascontiguousarray(x0), dtype=self.dt_t))
         self.pos.copy_(torch.as_tensor(np.tile(np.asarray(setpoint, float), (B, 1)), dtype=self.dt_t))
         self.yaw.fill_(float(yaw))
+        self.held.fill_(self.hover)
         side = torch.cuda.Stream(self.x.device) if use_graph else torch.cuda.current_stream()
         side.wait_stream(torch.cuda.current_stream())
         xs = torch.empty(steps + 1 if log else 1, B, 13, dtype=self.dt_t, device=self.x.device)

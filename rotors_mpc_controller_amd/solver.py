@@ -139,6 +139,10 @@ class NmpcOcpSolver:
             self._h, int(B), u_ptr, float(rotor_force_constant), float(motor_min_speed), float(motor_max_speed),
             speeds_ptr, clipped_ptr or None, stream or None))
 
+    def hold_command_device(self, B: int, u0_ptr: int, status_ptr: int, held_ptr: int, stream: int = 0) -> None:
+        """nodes/mpc_controller_node:122-131 batched: held [B,4] <- clip(u0) where status == 0, else unchanged."""
+        self._check(self._lib.nmpc_hold_command_device(self._h, int(B), u0_ptr, status_ptr, held_ptr, stream or None))
+
     def plant_step_device(self, B: int, x_ptr: int, u_ptr: int, x_next_ptr: int, normalize_q: bool = True,
                           stream: int = 0) -> None:
         """One interval of the controller's own model/ERK as the plant of a closed-loop rollout."""

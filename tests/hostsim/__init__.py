@@ -2,6 +2,7 @@
 from __future__ import annotations
 
 import ctypes as C
+import os
 import subprocess
 from pathlib import Path
 
@@ -17,10 +18,13 @@ _lib = None
 def lib():
     global _lib
     if _lib is None:
-        so = _HERE / "libnmpc_hostsim.so"
+        san = os.environ.get("NMPC_SANITIZE") == "1"     # ASan + UBSan build of the kernel bodies (CPU only)
+        so = _HERE / ("libnmpc_hostsim_asan.so" if san else "libnmpc_hostsim.so")
         deps = [_HERE / "hostsim.cpp"] + sorted((_ROOT / "rotors_mpc_controller_amd" / "csrc").glob("*.hpp"))
         if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+            flags = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
+                     if san else ["-O2"])
+            subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-o", str(so), str(_HERE / "hostsim.cpp")])
         _lib = C.CDLL(str(so))
         dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int32)

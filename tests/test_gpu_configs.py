@@ -1,0 +1,178 @@
+"""GPU tests (-m gpu) of the BASELINE.json configurations that need their full size, of the acados-version
+discriminator K2 on the device, and of the failure hand-back.
+
+  config 3: batch = 65536 Monte-Carlo initial states, N = 20, FP32  (seed 1)
+  config 5: horizon 600, batch = 1024, FP64                          (seed 5)
+
+At full size the checks are the size-independent properties the domain offers (bounds, initial-state pin,
+permutation equivariance, broadcast == materialised reference); the oracle runs on a sample that it finishes in
+seconds.  Tolerances are stated next to each assertion.
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+from rotors_mpc_controller_amd import _lib
+from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
+
+pytestmark = pytest.mark.gpu
+
+
+def make_solver(**over):
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    over.setdefault("max_batch", 512)
+    return NmpcOcpSolver(_lib.default_config(**over))
+
+
+def hover(cfg):
+    return hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
+
+
+def test_config3_fp32_batch_65536_properties_and_oracle_sample():
+    """FP32 arithmetic end to end (device buffers, linearisation, Riccati sweeps, active-set polish with the
+    FP32 KKT tolerance 1e-5).  Tolerance vs the FP64 oracle on the same (float32-representable) inputs:
+    5e-5 N on u0 -- thrusts are O(1) N, i.e. 3e-5 relative; measured ~3e-6."""
+    B = 65536
+    s = make_solver(dtype=_lib.DTYPE_F32, max_batch=B)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(B, 1, **NEAR_HOVER).astype(np.float32).astype(np.float64)   # what the device really sees
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    st = s.stats()
+    assert st["batch"] == B
+    assert (out["status"] == 0).all()
+    assert np.isfinite(out["u"]).all() and np.isfinite(out["x"]).all()
+    lbu, ubu = np.array(s.config.lbu), np.array(s.config.ubu)
+    assert (out["u"] >= lbu - 1e-5).all() and (out["u"] <= ubu + 1e-5).all()      # FP32 bound tolerance
+    np.testing.assert_array_equal(out["x"][:, 0], x0)                            # x0 pin (U7), exact
+    np.testing.assert_array_equal(out["u0"], out["u"][:, 0])
+    # instances are independent: a permuted batch returns the permuted commands, bit for bit
+    perm = np.random.default_rng(1).permutation(B)
+    out_p = s.solve_batch(x0[perm], yref, ye)
+    np.testing.assert_array_equal(out_p["u0"], out["u0"][perm])
+    # oracle on every 64th instance (1024 instances)
+    idx = np.arange(0, B, 64)
+    ref = O.solve_batch(O.default_config(qp_gamma=0.0, qp_polish=1), x0[idx], yref, ye)
+    assert (ref["status"] == 0).all()
+    err = np.abs(out["u0"][idx] - ref["u0"]).max()
+    assert err < 5e-5, err
+
+
+def test_config3_fp32_materialised_reference_matches_broadcast():
+    """[B,N,17] references (the 'coalesced batched reference loads' case of SURVEY 8d) against the broadcast
+    [N,17] form, FP32, on a slice of config 3 (the full tile would be 178 MB of host doubles twice)."""
+    B = 8192
+    s = make_solver(dtype=_lib.DTYPE_F32, max_batch=B)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(65536, 1, **NEAR_HOVER)[:B].astype(np.float32).astype(np.float64)
+    a = s.solve_batch(x0, yref, ye)
+    b = s.solve_batch(x0, np.tile(yref, (B, 1, 1)), np.tile(ye, (B, 1)))
+    np.testing.assert_array_equal(a["u0"], b["u0"])
+    np.testing.assert_array_equal(a["status"], b["status"])
+
+
+def test_config5_horizon_600_batch_1024():
+    """N = 600 (cfg/rotors_mpc.cfg:9 maximum), B = 1024, FP64, near-hover seed 5.  Oracle on 32 instances:
+    equal status, |u0 - oracle| <= 1e-8 N, trajectories <= 1e-6 (600 stages accumulate rounding-order
+    differences of the two Riccati implementations); full size: bounds, x0 pin, dynamics-consistent
+    trajectory, permutation equivariance."""
+    N, B = 600, 1024
+    s = make_solver(N=N, max_batch=B)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(B, 5, **NEAR_HOVER)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    assert (out["status"] == 0).all()
+    lbu, ubu = np.array(s.config.lbu), np.array(s.config.ubu)
+    assert (out["u"] >= lbu - 1e-9).all() and (out["u"] <= ubu + 1e-9).all()
+    np.testing.assert_array_equal(out["x"][:, 0], x0)
+    idx = np.arange(0, B, 32)
+    c = O.default_config(N=N, qp_gamma=0.0, qp_polish=1)
+    ref = O.solve_batch(c, x0[idx], yref, ye, want_traj=True)
+    np.testing.assert_array_equal(out["status"][idx], ref["status"])
+    np.testing.assert_allclose(out["u0"][idx], ref["u0"], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(out["u"][idx], ref["u"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(out["x"][idx], ref["x"], rtol=0, atol=1e-6)
+    # the QP solution is unique: the plain interior-point path of the oracle lands on the same command
+    ref_ipm = O.solve_batch(O.default_config(N=N, qp_gamma=0.0, qp_polish=0), x0[idx[:8]], yref, ye)
+    np.testing.assert_allclose(out["u0"][idx[:8]], ref_ipm["u0"], rtol=0, atol=1e-7)
+    perm = np.random.default_rng(5).permutation(B)
+    out_p = s.solve_batch(x0[perm], yref, ye)
+    np.testing.assert_array_equal(out_p["u0"], out["u0"][perm])
+
+
+@pytest.mark.parametrize("lm_scaled", [1, 0])
+def test_k2_hover_lm_discriminator_on_gpu(lm_scaled):
+    """K2: hover state, hover reference, lambda = 7e-3.  The Levenberg-Marquardt term penalises the
+    step from the linearisation point (u = 0, x_k = x0), so u0 is uniformly OFF m g / 4: by ~3.4e-4 N when
+    acados scales the term by dt on the stages (lm_scaled_by_dt = 1) and by ~6.4e-3 N when it does not -- the
+    version discriminator (SURVEY 8c quotes the magnitudes).  GPU vs oracle 1e-12; the magnitudes to 5 %."""
+    hov = 0.68 * 9.81 / 4.0
+    xh = np.zeros(13); xh[2] = 1.0; xh[6] = 1.0
+    s = make_solver(lm_scaled_by_dt=lm_scaled, max_batch=4)
+    yref, ye = hover(s.config)
+    out = s.solve_batch(xh[None], yref, ye)
+    ref = O.solve_batch(O.default_config(qp_gamma=0.0, qp_polish=1, lm_scaled_by_dt=lm_scaled), xh[None], yref, ye)
+    assert out["status"][0] == 0
+    np.testing.assert_allclose(out["u0"], ref["u0"], rtol=0, atol=1e-12)
+    assert np.ptp(out["u0"]) < 1e-12                                    # uniform over the rotors
+    off = abs(out["u0"][0, 0] - hov)
+    want = 3.4e-4 if lm_scaled else 6.4e-3
+    assert abs(off - want) < 0.05 * want, off
+
+
+@pytest.mark.parametrize("share", [True, False])
+def test_failed_instance_hands_back_cold_start_and_recovers(share):
+    """A failed instance (status != 0) must return zeros as its command (controller.py:448-450) and the
+    cold-start point (x_k = x0, u_k = 0, controller.py:425-431) as its trajectories -- never stale workspace
+    memory -- so that the next warm-started tick restarts that instance cold and recovers."""
+    B = 37
+    s = make_solver(flags=(1 if share else 0) | _lib.FLAG_TEAM_MAPPING, max_batch=64)
+    c = O.default_config(qp_gamma=0.0, qp_polish=1)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(B, 13, **AGGRESSIVE)
+    first = s.solve_batch(x0, yref, ye, want_traj=True)
+    assert (first["status"] == 0).all()
+    # tick 2: the warm start of instance 5 is poisoned -> its linearisation is NaN -> status 1
+    x1 = x0 + np.random.default_rng(13).normal(0, 0.01, x0.shape)
+    xi, ui = first["x"].copy(), first["u"].copy()
+    xi[5, 7, 3] = np.nan
+    out = s.solve_batch(x1, yref, ye, x_init=xi, u_init=ui, want_traj=True)
+    assert out["status"][5] == 1 and (np.delete(out["status"], 5) == 0).all()
+    np.testing.assert_array_equal(out["u0"][5], 0.0)
+    np.testing.assert_array_equal(out["x"][5], np.tile(x1[5], (s.N + 1, 1)))
+    np.testing.assert_array_equal(out["u"][5], 0.0)
+    assert np.isfinite(out["x"]).all() and np.isfinite(out["u"]).all()
+    ref = O.solve_batch(c, x1, yref, ye, x_init=xi, u_init=ui, want_traj=True)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_allclose(out["x"], ref["x"], rtol=0, atol=1e-8)
+    # tick 3, warm-started from what tick 2 handed back: every instance succeeds again; instance 5 has
+    # restarted from the cold-start point and equals the oracle's solve from that point
+    x2 = x1 + np.random.default_rng(14).normal(0, 0.01, x0.shape)
+    out3 = s.solve_batch(x2, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
+    ref3 = O.solve_batch(c, x2, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True)
+    assert (out3["status"] == 0).all()
+    np.testing.assert_allclose(out3["u0"], ref3["u0"], rtol=0, atol=1e-8)
+    # the cold start with a NaN initial state under the shared linearisation: zeros and status 1, neighbours intact
+    xb = x0.copy(); xb[9, 2] = np.nan
+    o = s.solve_batch(xb, yref, ye, want_traj=True)
+    assert o["status"][9] == 1 and (np.delete(o["status"], 9) == 0).all()
+    np.testing.assert_array_equal(o["u0"][9], 0.0)
+    np.testing.assert_array_equal(o["u"][9], 0.0)
+    np.testing.assert_allclose(np.delete(o["u0"], 9, 0), np.delete(first["u0"], 9, 0), rtol=0, atol=1e-12)
+
+
+def test_hold_command_kernel_mirrors_the_node():
+    """nodes/mpc_controller_node:122-131,152-164: a successful solve publishes its clipped command and
+    remembers it; a failed one re-publishes the remembered command."""
+    import torch
+    s = make_solver(max_batch=64)
+    B = 50
+    rng = np.random.default_rng(2)
+    u0 = rng.uniform(-1.0, 8.0, (B, 4))
+    held = rng.uniform(0.5, 5.0, (B, 4))
+    status = (rng.uniform(size=B) < 0.3).astype(np.int32) * rng.integers(1, 5, B).astype(np.int32)
+    d_u, d_h, d_s = torch.from_numpy(u0).cuda(), torch.from_numpy(held).cuda(), torch.from_numpy(status).cuda()
+    s.hold_command_device(B, d_u.data_ptr(), d_s.data_ptr(), d_h.data_ptr())
+    torch.cuda.synchronize()
+    lbu, ubu = np.array(s.config.lbu), np.array(s.config.ubu)
+    want = np.where((status == 0)[:, None], np.clip(u0, lbu, ubu), held)
+    np.testing.assert_array_equal(d_h.cpu().numpy(), want)

@@ -14,4 +14,5 @@ print(f"[{sys.argv[1]:32s}] {d['value']/1e6:8.3f} M/s  step {d['ms_per_step']:.4
       f"ipm {d['ipm_iterations']['mean']:.2f}/{d['ipm_iterations']['max']}  pol {d['active_set_passes']['mean']:.3f}/{d['active_set_passes']['max']}  st {d['status_histogram']}")
 PY
 done
-python tools/profile_sweeps.py > gpurun_out/prof_sweeps.txt 2>gpurun_out/prof_sweeps.err; tail -9 gpurun_out/prof_sweeps.txt; if grep -q "core dump" gpurun_out/prof_sweeps.txt gpurun_out/prof_sweeps.err; then echo "GPU FAULT in profile_sweeps"; exit 1; fi
+make -s -C rotors_mpc_controller_amd/csrc prof
+python tools/profile_sweeps.py > gpurun_out/prof_sweeps.txt 2>gpurun_out/prof_sweeps.err || { echo "profile_sweeps.py FAILED"; tail -5 gpurun_out/prof_sweeps.err; exit 1; }; tail -9 gpurun_out/prof_sweeps.txt; if grep -q "core dump" gpurun_out/prof_sweeps.txt gpurun_out/prof_sweeps.err; then echo "GPU FAULT in profile_sweeps"; exit 1; fi
