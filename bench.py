@@ -14,9 +14,10 @@ FP64, hover reference materialised per instance ([B,N,17]).
 from __future__ import annotations
 
 import argparse
-import ctypes
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 from pathlib import Path
@@ -77,6 +78,112 @@ def cpu_baseline(B_sample: int, N: int):
                      single_thread_value=n1 / dt_1)
 
 
+def source_hash() -> str:
+    """sha1 over the kernel sources: ties a committed PMC summary to the build it was captured on."""
+    h = hashlib.sha1()
+    for f in sorted((ROOT / "rotors_mpc_controller_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
+def relaunch_under_torchrun(n: int) -> None:
+    """`python bench.py --gpus N` without a launcher: start the N ranks as a CHILD process group (before
+    anything here has touched the GPU) and relay its output; the child ranks see WORLD_SIZE = N."""
+    port = 29500 + (os.getpid() % 2000)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve())] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd))
+
+
+def timed_rate(solver, B, launch, steps, warmup, torch, dev):
+    """solves/s and ms per step of `launch()` repeated `steps` times (device-resident inputs, one stream)."""
+    for _ in range(warmup):
+        launch()
+    torch.cuda.synchronize(dev)
+    t = time.perf_counter()
+    for _ in range(steps):
+        launch()
+    torch.cuda.synchronize(dev)
+    el = (time.perf_counter() - t) / steps
+    return B / el, 1e3 * el
+
+
+def secondary_rows(args, B, N, local, dev, tdt, npdt, torch, _lib, NmpcOcpSolver, x0_h, yref, yref_e, bcast):
+    """The rows SURVEY 8(d) wants next to the headline ("report with and without" the shared cold start; the
+    plain interior-point path, which is what the reference's HPIPM does; the aggressive initial-state set):
+    same batch, same inputs unless stated, measured after the timed region."""
+    from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, sample_x0
+    rows = {}
+    x0_aggr = torch.from_numpy(sample_x0(B, 0, **AGGRESSIVE).astype(npdt)).to(dev)
+    x0_near = torch.from_numpy(x0_h.astype(npdt)).to(dev)
+    u0 = torch.zeros(B, 4, dtype=tdt, device=dev)
+    status = torch.zeros(B, dtype=torch.int32, device=dev)
+    stream = torch.cuda.current_stream(dev)
+    variants = [("no_share", dict(flags=_lib.FLAG_TEAM_MAPPING), x0_near, "per-stage linearisation (what every warm-started tick runs)"),
+                ("plain_ipm", dict(qp_polish=0), x0_near, "qp_polish = 0: Mehrotra interior point only, no active-set passes"),
+                ("aggressive", dict(), x0_aggr, "aggressive x0 set (SURVEY 8d), seed 0: ~28 % of the instances hit a bound")]
+    for name, over, x0, what in variants:
+        cfg = _lib.default_config(N=N, max_batch=B, device=local, dtype=_lib.DTYPE_F64 if args.dtype == "f64" else _lib.DTYPE_F32)
+        if args.dtype == "f32":
+            cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
+        cfg.update(**over)
+        sv = NmpcOcpSolver(cfg)
+        sv.set_timing(False)
+
+        def launch(sv=sv, x0=x0):
+            sv.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0.data_ptr(),
+                                  status_ptr=status.data_ptr(), stream=stream.cuda_stream)
+        rate, ms = timed_rate(sv, B, launch, max(10, args.steps // 4), 5, torch, dev)
+        sv.set_timing(True)
+        launch()
+        st = sv.stats()
+        rows[name] = dict(value=rate, unit="solves/s", ms_per_step=ms, what=what,
+                          ipm_iterations_mean=st["iter_mean"], ipm_iterations_max=st["iter_max"],
+                          active_set_passes_mean=st["polish_mean"], active_set_passes_max=st["polish_max"],
+                          status_histogram=st["n_status"])
+        sv.close()
+    return rows
+
+
+def latency_config1(local, _lib):
+    """BASELINE.json configs[0] / BASELINE.md run C0: ONE instance, hover setpoint, the way the reference uses
+    its solver (60 Hz, config/params.yaml:48).  Median wall time of (a) bare nmpc_solve() on the
+    single-instance slot (linearisation point and references already set), (b) the whole
+    PositionNMPC.solve(state, reference) facade call (64 set + solve + 42 get equivalents, warm-started)."""
+    import statistics
+    from rotors_mpc_controller_amd.controller import PositionNMPC
+    from rotors_mpc_controller_amd.params import load_params
+    from rotors_mpc_controller_amd.reference import ReferenceGenerator
+    params = load_params()
+    ctl = PositionNMPC(params, max_batch=1, device=local)
+    gen = ReferenceGenerator(params["reference"])
+    gen.update_hover_thrust(ctl.hover_thrust)
+    ref = gen.build_horizon(ctl.horizon, ctl.dt)
+    state = dict(position=np.array([0.0, 0.0, 0.5]), velocity=np.zeros(3), quaternion=np.array([1.0, 0, 0, 0]), body_rates=np.zeros(3))
+    sv = ctl._solver
+    sv.set_timing(False)
+    for _ in range(20):
+        ctl.solve(state, ref)
+    tf, tb, ts = [], [], []
+    for _ in range(200):
+        t = time.perf_counter(); u, stt = ctl.solve(state, ref); tf.append(time.perf_counter() - t)
+        assert stt == 0
+    ctl._one_call = False            # the reference's own call sequence: 64 set + solve + 42 get per tick
+    for _ in range(20):
+        ctl.solve(state, ref)
+    for _ in range(200):
+        t = time.perf_counter(); u, stt = ctl.solve(state, ref); ts.append(time.perf_counter() - t)
+        assert stt == 0
+    for _ in range(200):
+        t = time.perf_counter(); rc = sv.solve(); tb.append(time.perf_counter() - t)
+        assert rc == 0
+    return dict(bare_nmpc_solve=1e6 * statistics.median(tb), facade_PositionNMPC_solve=1e6 * statistics.median(tf),
+                facade_reference_call_sequence=1e6 * statistics.median(ts),
+                samples=200, statistic="median", workload="B = 1, hover setpoint, x0 = (0,0,0.5), N = 20, FP64, warm start",
+                note="host wall time incl. two pinned-memory copies and one stream synchronisation per solve")
+
+
 def main() -> None:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,13 +201,21 @@ def main() -> None:
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--per-solve-events", action="store_true",
                     help="keep the library's own HIP events around every solve inside the timed region")
-    ap.add_argument("--gather-every", type=int, default=8,
-                    help="multi-GPU: ticks whose u0 share one RCCL all-gather (1 = a collective per tick)")
+    ap.add_argument("--gather-every", type=int, default=1,
+                    help="multi-GPU: ticks whose u0 share one RCCL all-gather (1 = a collective per tick, the default; "
+                         "8 = the batched exchange, reported as a secondary row when N > 1)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the secondary rows and the config-1 latency")
     ap.add_argument("--no-polish", action="store_true", help="plain interior point iteration (qp_polish = 0)")
     ap.add_argument("--condensed", action="store_true", help="partial-condensing kernel (NMPC_FLAG_CONDENSED_QP)")
     ap.add_argument("--polish-ckpt", type=int, default=None, help="override nmpc_config.qp_polish_ckpt")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
+
+    world_env = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world_env:
+        if world_env == 1 and args.gpus > 1:
+            relaunch_under_torchrun(args.gpus)            # never returns
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {world_env}")
 
     import torch
     import torch.distributed as dist
@@ -249,12 +364,17 @@ def main() -> None:
         # HBM-side bytes per launch from the committed rocprofv3 --pmc passes of the SAME command
         # (tools/rocprof_capture.sh); FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per the
         # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
-        traffic = None
+        traffic, traffic_note = None, None
         kname = "k_team_ipm" if args.mapping == "team" else "k_ipm"
         pmc_file = ROOT / "profiles" / f"latest_{args.mapping}_b{B}_{args.dtype}_pmc_summary.json"
         if pmc_file.exists() and not args.no_share and not bcast and not args.traj_out and N == 20:
-            pmc = json.loads(pmc_file.read_text()).get(kname, {})
-            if "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
+            pmc_all = json.loads(pmc_file.read_text())
+            pmc = pmc_all.get(kname, {})
+            # quoted only when the summary was captured on THIS build of the kernels (tools/summarize_pmc.py
+            # records the hash of the kernel sources); otherwise null + a note, never a stale figure
+            if pmc_all.get("source_hash") != source_hash():
+                traffic_note = f"stale profile: {pmc_file.name} was captured on kernel sources {pmc_all.get('source_hash')}, this build is {source_hash()}"
+            elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
         kernel_name = "k_team_ipm" if args.mapping == "team" else "k_ipm"
         hbm = dict(achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS,
@@ -272,13 +392,13 @@ def main() -> None:
         # every other variant is a vector-ALU kernel and keeps the HBM line of the contract, with the flop
         # figures beside it.  Both sub-objects are always present.
         mfma_path = args.mapping == "team" and args.dtype == "f64" and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
-        common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else None),
+        common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else traffic_note),
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"], prepare_ms=st["ms_prepare"], hbm=hbm, alu=flop)
         if mfma_path:
             roof = dict(bound="mfma", achieved=alu_x_tf, peak=f_peak, unit="TFLOP/s", frac=alu_x_tf / f_peak, **common)
         else:
             roof = dict(bound="hbm", achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS, **common)
-        line = dict(metric="NMPC SQP-RTI solves/sec (N=20, nx=13, nu=4) at batch=4096 per GPU",
+        line = dict(metric=f"NMPC SQP-RTI solves/sec (N={N}, nx=13, nu=4) at batch={B} per GPU",
                     value=rate, unit="solves/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=ms_step, device_ms_per_step=dev_ms, higher_is_better=True, scaling="weak",
                     vs_baseline=None, dtype=args.dtype, data="synthetic",
@@ -296,6 +416,46 @@ def main() -> None:
             ok = (status_h[:ns] == 0) & (ref["status"] == 0)
             line["max_abs_u0_vs_oracle"] = float(np.abs(u0_h[:ns][ok] - ref["u0"][ok]).max())
             line["parity_note"] = "vs build CPU oracle; acados parity unpinned (SURVEY 8c)"
+        line["source_hash"] = source_hash()
+    # ---- rows measured AFTER the timed region (never part of `value`)
+    if use_dist and G == 1 and not args.no_secondary:
+        # the batched exchange: u0 of 8 consecutive ticks share one asynchronous all-gather
+        G8 = 8
+        u0g8 = [torch.zeros(G8, B, 4, dtype=tdt, device=dev) for _ in range(2)]
+        gat8 = [torch.zeros(world, G8, B, 4, dtype=tdt, device=dev) for _ in range(2)]
+        pend8 = [None, None]
+        solver.set_timing(False)
+
+        def run8(n):
+            for t in range(n):
+                k, slot = (t // G8) & 1, t % G8
+                if slot == 0 and pend8[k] is not None:
+                    pend8[k].wait(); pend8[k] = None
+                solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0g8[k][slot].data_ptr(),
+                                          status_ptr=status.data_ptr(), stream=stream.cuda_stream)
+                if slot == G8 - 1:
+                    pend8[k] = dist.all_gather_into_tensor(gat8[k].view(world * G8 * B, 4), u0g8[k].view(G8 * B, 4), async_op=True)
+            for k in (0, 1):
+                if pend8[k] is not None:
+                    pend8[k].wait(); pend8[k] = None
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        run8(2 * G8)
+        n8 = max(2 * G8, (args.steps // (2 * G8)) * 2 * G8)
+        t8 = time.perf_counter()
+        run8(n8)
+        e8 = torch.tensor([time.perf_counter() - t8], dtype=torch.float64, device=dev)
+        dist.all_reduce(e8, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            line.setdefault("secondary", {})["gather_every_8"] = dict(
+                value=world * B / (float(e8.item()) / n8), unit="solves/s", ms_per_step=1e3 * float(e8.item()) / n8,
+                what="u0 of 8 consecutive ticks share one asynchronous RCCL all-gather (fewer, larger collectives)")
+    if rank == 0:
+        if world == 1 and not args.no_secondary and args.mapping == "team" and not args.condensed:
+            sec = secondary_rows(args, B, N, local, dev, tdt, npdt, torch, _lib, NmpcOcpSolver, x0_h, yref, yref_e, bcast)
+            line.setdefault("secondary", {}).update(sec)
+            if args.dtype == "f64":
+                line["latency_us"] = latency_config1(local, _lib)
         print(json.dumps(line), flush=True)
     if use_dist:
         dist.destroy_process_group()

@@ -88,20 +88,38 @@ def build(force: bool = False) -> Path:
 _lib = None
 
 
+def _bind_one_hip_runtime() -> None:
+    """One HIP runtime per process, whatever the import order.
+
+    PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64 (torch/lib, SONAME libamdhip64.so.7 -- the
+    same SONAME this library's DT_NEEDED names).  Two copies in one process each run their own device
+    discovery and the second one finds no device (observed on the GPU box), and a pointer allocated through one
+    must never reach the other.  So, without importing torch: if a torch installation exists and has not been
+    imported yet, map ITS runtime first with RTLD_GLOBAL.  The dynamic linker then resolves this library's
+    DT_NEEDED to that already-loaded object, and a later `import torch` finds the same file mapped: one runtime
+    in either order.  Without torch installed the library binds to /opt/rocm's copy through its RUNPATH.
+    (A C program that links this library and never loads torch is in the second case by construction.)"""
+    import importlib.util
+    import sys
+    if "torch" in sys.modules:
+        return                                   # torch has mapped its runtime already
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = Path(spec.origin).parent / "lib" / "libamdhip64.so"
+    if cand.exists():
+        C.CDLL(str(cand), mode=C.RTLD_GLOBAL)
+
+
 def load() -> C.CDLL:
     """Load the HIP library.  Never falls back: a missing library is an error."""
     global _lib
     if _lib is not None:
         return _lib
-    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64/libhsa-runtime64.
-    # If this library were loaded first it would pull in /opt/rocm's copies, and a later
-    # `import torch` would bring a second runtime whose device discovery then fails
-    # (observed on the GPU box: hipGetDeviceCount -> no device).  Importing torch first makes
-    # the dynamic linker resolve our DT_NEEDED libamdhip64.so.7 to torch's already-loaded one.
-    try:
-        import torch  # noqa: F401
-    except ImportError:
-        pass
+    _bind_one_hip_runtime()
     path = Path(os.environ.get("ROTORS_NMPC_LIB", LIB_PATH))
     if not path.exists():
         raise RuntimeError(

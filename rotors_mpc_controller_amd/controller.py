@@ -100,7 +100,12 @@ class PositionNMPC:
     """Nonlinear MPC for the rotor-level quadrotor model, solved on the GPU."""
 
     def __init__(self, params: Mapping[str, Mapping[str, object]], *, max_batch: int = 1, device: int = 0,
-                 dtype: int = _lib.DTYPE_F64, solver_factory=None, **solver_overrides) -> None:
+                 dtype: int = _lib.DTYPE_F64, solver_factory=None, one_call: bool = True, **solver_overrides) -> None:
+        # one_call: a tick crosses the Python -> C boundary once (nmpc_solve_batch with B = 1: linearisation
+        # point, references, solve, trajectories) instead of the reference's 64 set + 1 solve + 42 get
+        # round trips (controller.py:412-460, SURVEY 3.1) -- same arrays, same results; one_call=False keeps
+        # the reference's call sequence (also used automatically for a solver object without solve_batch)
+        self._one_call = bool(one_call)
         # solver_factory(NmpcConfig) -> object with set/solve/get/close; default: the HIP library.
         # (Tests inject an oracle-backed stand-in to exercise this class without a GPU.)
         self._solver_factory = solver_factory or NmpcOcpSolver
@@ -169,6 +174,22 @@ class PositionNMPC:
     def solve(self, state: Mapping[str, np.ndarray], reference: Mapping[str, np.ndarray]) -> Tuple[np.ndarray, int]:
         N, s = self.config.horizon_steps, self._solver
         x0 = self._state_vector(state)
+        if self._one_call and hasattr(s, "solve_batch"):
+            yref, yref_e = stack_yref(reference, N)
+            if self._prev_solution_valid:        # previous solution, not shifted; stage 0 is pinned to x0 (:416)
+                xi = self._prev_solution["x"][None].copy()
+                xi[0, 0] = x0
+                out = s.solve_batch(x0[None], yref, yref_e, xi, self._prev_solution["u"][None], want_traj=True)
+            else:                                # cold start: x_k = x0, u_k = 0 (:425-431)
+                out = s.solve_batch(x0[None], yref, yref_e, want_traj=True)
+            status = int(out["status"][0])
+            if status != 0:
+                self._prev_solution_valid = False
+                return np.zeros(self.nu), status
+            self._prev_solution["x"][:] = out["x"][0]
+            self._prev_solution["u"][:] = out["u"][0]
+            self._prev_solution_valid = True
+            return out["u0"][0].copy(), status
         s.set(0, "lbx", x0)
         s.set(0, "ubx", x0)
         s.set(0, "x", x0)

@@ -91,6 +91,12 @@ struct nmpc_solver {
     void *s_x0 = nullptr, *s_yref = nullptr, *s_yref_e = nullptr, *s_xi = nullptr, *s_ui = nullptr;
     void *s_u0 = nullptr, *s_xo = nullptr, *s_uo = nullptr;
     size_t staged_batch = 0;
+    // small batches (and the single-instance nmpc_solve): ONE pinned host block in, one out, one device block
+    // each, two asynchronous copies on the solver's own stream instead of up to nine pageable ones
+    static constexpr int PACK_B = 64;
+    void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
+    size_t pack_in_bytes = 0, pack_out_bytes = 0;
+    hipStream_t pack_stream = nullptr;
     uint64_t ws_bytes = 0;
     hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
     int last_B = 0;
@@ -98,6 +104,8 @@ struct nmpc_solver {
     bool timing = true;   // nmpc_set_timing: HIP events around the kernels of every solve
     // single-instance slot (AcadosOcpSolver.set/get state)
     std::vector<double> sx, su, syref, syref_e, sx0;
+    std::vector<float> cvt;   // FP32 conversions of the host-buffer entry point
+    std::vector<double> sxo, suo;   // result slot of nmpc_solve (swapped in on success)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
@@ -283,6 +291,11 @@ void nmpc_destroy(nmpc_solver *s)
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    if (s->d_in) (void)hipFree(s->d_in);
+    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->h_in) (void)hipHostFree(s->h_in);
+    if (s->h_out) (void)hipHostFree(s->h_out);
+    if (s->pack_stream) (void)hipStreamDestroy(s->pack_stream);
     for (auto &e : s->ev)
         if (e) (void)hipEventDestroy(e);
     delete s;
@@ -424,9 +437,9 @@ static int h2d(nmpc_solver *s, void *dst, const double *src, size_t n)
     if (s->esz == 8) {
         HIP_TRY(s, hipMemcpy(dst, src, n * 8, hipMemcpyHostToDevice));
     } else {
-        std::vector<float> tmp(n);
-        for (size_t i = 0; i < n; i++) tmp[i] = (float)src[i];
-        HIP_TRY(s, hipMemcpy(dst, tmp.data(), n * 4, hipMemcpyHostToDevice));
+        if (s->cvt.size() < n) s->cvt.resize(n);         // persistent conversion buffer: grows, never shrinks
+        for (size_t i = 0; i < n; i++) s->cvt[i] = (float)src[i];
+        HIP_TRY(s, hipMemcpy(dst, s->cvt.data(), n * 4, hipMemcpyHostToDevice));
     }
     return 0;
 }
@@ -436,10 +449,67 @@ static int d2h(nmpc_solver *s, double *dst, const void *src, size_t n)
     if (s->esz == 8) {
         HIP_TRY(s, hipMemcpy(dst, src, n * 8, hipMemcpyDeviceToHost));
     } else {
-        std::vector<float> tmp(n);
-        HIP_TRY(s, hipMemcpy(tmp.data(), src, n * 4, hipMemcpyDeviceToHost));
-        for (size_t i = 0; i < n; i++) dst[i] = (double)tmp[i];
+        if (s->cvt.size() < n) s->cvt.resize(n);
+        HIP_TRY(s, hipMemcpy(s->cvt.data(), src, n * 4, hipMemcpyDeviceToHost));
+        for (size_t i = 0; i < n; i++) dst[i] = (double)s->cvt[i];
     }
+    return 0;
+}
+
+// host doubles -> element type of the device buffers, into (pinned) staging memory
+static void pack_put(size_t esz, void *dst, const double *src, size_t n)
+{
+    if (esz == 8) std::memcpy(dst, src, n * 8);
+    else { float *d = (float *)dst; for (size_t i = 0; i < n; i++) d[i] = (float)src[i]; }
+}
+static void pack_get(size_t esz, double *dst, const void *src, size_t n)
+{
+    if (esz == 8) std::memcpy(dst, src, n * 8);
+    else { const float *f = (const float *)src; for (size_t i = 0; i < n; i++) dst[i] = (double)f[i]; }
+}
+
+// Latency path (B <= PACK_B; config 1 of BASELINE.json is B = 1 at 60 Hz, config/params.yaml:48): everything
+// the solve reads travels in one pinned block and one H2D copy, everything it writes in one D2H copy, all on
+// the solver's own stream; one stream synchronisation at the end.
+static int solve_packed(nmpc_solver *s, int B, const double *x0, const double *yref, const double *yref_e,
+                        int yref_bcast, const double *x_init, const double *u_init, double *u0,
+                        int32_t *status, double *x_out, double *u_out)
+{
+    const size_t N = (size_t)s->cfg.N, e = s->esz, P = nmpc_solver::PACK_B;
+    if (!s->h_in) {
+        const size_t nin = P * (NX + N * NY + NX + (N + 1) * NX + N * NU), nout = P * (NU + (N + 1) * NX + N * NU);
+        s->pack_in_bytes = nin * e;
+        s->pack_out_bytes = nout * e + P * sizeof(int32_t) + 8;
+        HIP_TRY(s, hipStreamCreateWithFlags(&s->pack_stream, hipStreamNonBlocking));
+        HIP_TRY(s, hipHostMalloc(&s->h_in, s->pack_in_bytes, hipHostMallocDefault));
+        HIP_TRY(s, hipHostMalloc(&s->h_out, s->pack_out_bytes, hipHostMallocDefault));
+        HIP_TRY(s, hipMalloc(&s->d_in, s->pack_in_bytes));
+        HIP_TRY(s, hipMalloc(&s->d_out, s->pack_out_bytes));
+    }
+    const size_t Bs = (size_t)B, nyr = (yref_bcast ? 1 : Bs) * N * NY, nye = (yref_bcast ? 1 : Bs) * NX;
+    const bool warm = x_init != nullptr;
+    const size_t o_x0 = 0, o_yr = o_x0 + Bs * NX, o_ye = o_yr + nyr, o_xi = o_ye + nye, o_ui = o_xi + (warm ? Bs * (N + 1) * NX : 0),
+                 n_in = o_ui + (warm ? Bs * N * NU : 0);
+    char *hi = (char *)s->h_in, *di = (char *)s->d_in, *ho = (char *)s->h_out, *dO = (char *)s->d_out;
+    pack_put(e, hi + o_x0 * e, x0, Bs * NX);
+    pack_put(e, hi + o_yr * e, yref, nyr);
+    pack_put(e, hi + o_ye * e, yref_e, nye);
+    if (warm) { pack_put(e, hi + o_xi * e, x_init, Bs * (N + 1) * NX); pack_put(e, hi + o_ui * e, u_init, Bs * N * NU); }
+    const size_t q_u0 = 0, q_xo = q_u0 + Bs * NU, q_uo = q_xo + (x_out ? Bs * (N + 1) * NX : 0), n_out = q_uo + (u_out ? Bs * N * NU : 0);
+    const size_t q_st = (n_out * e + 7) / 8 * 8;                      // int32 status block, 8-byte aligned
+    hipStream_t st = s->pack_stream;
+    HIP_TRY(s, hipMemcpyAsync(di, hi, n_in * e, hipMemcpyHostToDevice, st));
+    const int rc = nmpc_solve_batch_device(s, B, di + o_x0 * e, di + o_yr * e, di + o_ye * e, yref_bcast,
+                                           warm ? di + o_xi * e : nullptr, warm ? di + o_ui * e : nullptr, dO + q_u0 * e,
+                                           (int32_t *)(dO + q_st), x_out ? dO + q_xo * e : nullptr,
+                                           u_out ? dO + q_uo * e : nullptr, st);
+    if (rc) return rc;
+    HIP_TRY(s, hipMemcpyAsync(ho, dO, q_st + Bs * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(s, hipStreamSynchronize(st));
+    pack_get(e, u0, ho + q_u0 * e, Bs * NU);
+    if (x_out) pack_get(e, x_out, ho + q_xo * e, Bs * (N + 1) * NX);
+    if (u_out) pack_get(e, u_out, ho + q_uo * e, Bs * N * NU);
+    if (status) std::memcpy(status, ho + q_st, Bs * sizeof(int32_t));
     return 0;
 }
 
@@ -452,6 +522,7 @@ int nmpc_solve_batch(nmpc_solver *s, int B, const double *x0, const double *yref
     if (!x0 || !yref || !yref_e || !u0) return s->fail(NMPC_EARG, "solve_batch: x0, yref, yref_e and u0 are required");
     if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "solve_batch: x_init and u_init must both be given or both be NULL");
     HIP_TRY(s, hipSetDevice(s->cfg.device));
+    if (B <= nmpc_solver::PACK_B) return solve_packed(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out);
     int rc = ensure_staging(s, (size_t)B);
     if (rc) return rc;
     const size_t N = (size_t)s->cfg.N, Bs = (size_t)B;
@@ -540,13 +611,13 @@ int nmpc_solve(nmpc_solver *s)
     const int N = s->cfg.N;
     double u0[NU];
     int32_t st = 0;
-    std::vector<double> xo((size_t)(N + 1) * NX), uo((size_t)N * NU);
+    if (s->sxo.empty()) { s->sxo.resize((size_t)(N + 1) * NX); s->suo.resize((size_t)N * NU); }
     // the linearisation point is whatever set('x'/'u') left in the slot (controller.py:416-431);
     // the stage-0 state is pinned to lbx_0 = ubx_0 (controller.py:414-415)
     const int rc = nmpc_solve_batch(s, 1, s->sx0.data(), s->syref.data(), s->syref_e.data(), 1, s->sx.data(),
-                                    s->su.data(), u0, &st, xo.data(), uo.data());
+                                    s->su.data(), u0, &st, s->sxo.data(), s->suo.data());
     if (rc) return rc;
-    if (st == 0) { s->sx = xo; s->su = uo; }
+    if (st == 0) { s->sx.swap(s->sxo); s->su.swap(s->suo); }
     return (int)st;
 }
 

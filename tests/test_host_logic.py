@@ -112,3 +112,24 @@ def test_derive_params_reproduces_survey_constants():
     bad["vehicle"]["rotor_configuration"] = "x"
     with pytest.raises(ValueError):
         derive_params(bad)
+
+
+def test_library_binds_one_hip_runtime_without_importing_torch():
+    """`_lib.load()` must not depend on `import torch` having happened first: it maps
+    torch's bundled HIP runtime itself when a torch installation exists, so that a later `import torch` finds
+    the same object -- exactly one libamdhip64 in the process in either order."""
+    import subprocess
+    import sys
+    code = (
+        "import sys\n"
+        "from rotors_mpc_controller_amd import _lib\n"
+        "lib = _lib.load()\n"
+        "assert 'torch' not in sys.modules, 'load() imported torch'\n"
+        "maps = lambda: sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "a = maps(); assert len(a) == 1, a\n"
+        "import torch\n"
+        "b = maps(); assert b == a, (a, b)\n"
+        "print('ok', a[0])\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
+                       cwd=str(__import__('pathlib').Path(__file__).resolve().parent.parent))
+    assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr + r.stdout

@@ -43,9 +43,12 @@ def test_facade_on_oracle_backend_reproduces_reference_controller(monkeypatch):
 
 
 @pytest.mark.gpu
-def test_facade_on_hip_backend_reproduces_reference_controller(monkeypatch):
+@pytest.mark.parametrize("one_call", [True, False])
+def test_facade_on_hip_backend_reproduces_reference_controller(monkeypatch, one_call):
+    """one_call=True: one C-ABI crossing per tick (nmpc_solve_batch, B = 1); False: the reference's own
+    set / solve / get sequence (controller.py:412-460).  Same commands either way."""
     monkeypatch.delenv("ROTORS_MPC_PARAMS", raising=False)
-    ctrl = PositionNMPC(load_params(), qp_polish=0)     # golden = reference controller on the plain-IPM oracle
+    ctrl = PositionNMPC(load_params(), qp_polish=0, one_call=one_call)     # golden = reference controller on the plain-IPM oracle
     _replay(ctrl, tol=1e-9)
 
 

@@ -27,6 +27,15 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"
         out.setdefault(k, {})[c] = dict(dispatches=len(v), mean=sum(v) / len(v))
     for k, m in meta.items():
         out.setdefault(k, {})["launch"] = m
+import hashlib
+import pathlib
+h = hashlib.sha1()
+for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "rotors_mpc_controller_amd" / "csrc").glob("*.h*")):
+    h.update(f.name.encode())
+    h.update(f.read_bytes())
+out["source_hash"] = h.hexdigest()[:12]      # bench.py quotes this traffic only on a build with the same hash
 json.dump(out, open(out_path, "w"), indent=1)
 for k, v in out.items():
+    if not isinstance(v, dict):
+        continue
     print(k, {c: round(x["mean"], 1) for c, x in v.items() if c != "launch"}, v.get("launch"))
