@@ -159,6 +159,11 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
 /* device-side IPM iteration counts of the last solve: int32 [B] DEVICE pointer (read-only) */
 const int32_t *nmpc_device_iterations(nmpc_solver *s);
 
+/* device-side active-set pass counts of the last solve (team mapping): int32 [B] DEVICE pointer (read-only);
+ * > 0: the instance ended on an accepted active-set solution after that many passes, <= 0: it did not
+ * (interior-point result), the magnitude being the passes spent                                          */
+const int32_t *nmpc_device_passes(nmpc_solver *s);
+
 /* synchronises, then fills iteration / status histograms and kernel times of the last solve */
 int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out);
 

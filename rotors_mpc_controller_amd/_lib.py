@@ -68,7 +68,7 @@ class NmpcStats(C.Structure):
 
 EXPORTS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
-    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_get_stats", "nmpc_set_timing",
+    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_stats", "nmpc_set_timing",
     "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
     "nmpc_hold_command_device",
@@ -77,7 +77,7 @@ EXPORTS = (
 
 def build(force: bool = False) -> Path:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_cond.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
+    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_team_as.hpp", "nmpc_cond.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
     srcs.append(_PKG.parent / "include" / "rotors_nmpc.h")
     stale = (not LIB_PATH.exists()) or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
@@ -146,6 +146,8 @@ def load() -> C.CDLL:
     lib.nmpc_solve_batch_device.restype = C.c_int
     lib.nmpc_device_iterations.argtypes = [vp]
     lib.nmpc_device_iterations.restype = vp
+    lib.nmpc_device_passes.argtypes = [vp]
+    lib.nmpc_device_passes.restype = vp
     lib.nmpc_get_stats.argtypes = [vp, C.POINTER(NmpcStats)]
     lib.nmpc_get_stats.restype = C.c_int
     lib.nmpc_set_timing.argtypes = [vp, C.c_int]

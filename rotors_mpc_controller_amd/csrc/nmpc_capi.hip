@@ -20,6 +20,7 @@
 #include "../../include/rotors_nmpc.h"
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
+#include "nmpc_team_as.hpp"
 #include "nmpc_cond.hpp"
 #include "nmpc_aux.hpp"
 #include "nmpc_consts.hpp"
@@ -76,6 +77,42 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
     team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry, SHARED && fused != 0);
 }
 
+// default FP64 path, first launch: preparation + the first active-set attempt (nmpc_team_as.hpp).
+// OCC = waves per SIMD the register allocation allows: 2 (256 registers) pays once the batch supplies two waves
+// per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
+template <bool SHARED, bool TRAJ, int OCC>
+__global__ __launch_bounds__(64, OCC) void k_team_as(Consts<double> c, Work<double> w, Inputs<double> in, Outputs<double> out,
+                                                     TeamWork<double> tw, WorkList wl, int B, int tpw)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    team_as<SHARED, TRAJ>(c, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw));
+}
+
+// default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
+// the instances the first launch appended to the work list - usually none.  A fixed small grid strides over the
+// list; the last workgroup to finish resets the list for the next solve.
+template <bool SHARED>
+__global__ __launch_bounds__(64, 1) void k_team_ipm_list(Consts<double> c, Work<double> w, Inputs<double> in, Outputs<double> out,
+                                                         TeamWork<double> tw, WorkList wl, int B)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    double *smem = reinterpret_cast<double *>(smem_raw);
+    const int n = *wl.count;
+    const int team = (threadIdx.x >> 2) & 3;
+    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+        const int e = base + team;
+        const int inst = e < n ? wl.list[e] : -1;
+        team_prepare(c, w, in, B, 4, smem, inst);
+        __syncthreads();
+        team_ipm<double, true, SHARED, true>(c, w, out, tw, B, 4, smem, 0ll, SHARED, inst, true);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(wl.done, 1);          // every workgroup has read the count before it arrives here
+        if (t == (int)gridDim.x - 1) { *wl.count = 0; *wl.done = 0; }
+    }
+}
+
 }  // namespace
 
 struct nmpc_solver {
@@ -86,6 +123,8 @@ struct nmpc_solver {
     // device workspace (element type = cfg.dtype)
     void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *tP = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
+    int *d_wl = nullptr;             // work list of the split FP64 path: count | done | list [Bp]
+    int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
     void *s_x0 = nullptr, *s_yref = nullptr, *s_yref_e = nullptr, *s_xi = nullptr, *s_ui = nullptr;
@@ -188,18 +227,21 @@ static int ckpt_stages(const nmpc_config &g)
 static int alloc_ws(nmpc_solver *s)
 {
     const size_t N = (size_t)s->cfg.N, Bp = (size_t)s->Bp, e = s->esz;
+    const size_t Bw = Bp + 1;      // per-instance team workspaces carry one spare row: idle teams of a wave work there
     struct { void **p; size_t n; } a[] = {
         {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
-        {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bp * e},
-        {&s->iv, N * IV_ROWS * Bp * e},
-        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bp : 1) * e},
-        {&s->tP, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bp : 1) * e},
+        {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bw * e},
+        {&s->iv, N * IV_ROWS * Bw * e},
+        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bw : 1) * e},
+        {&s->tP, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bw : 1) * e},
         {(void **)&s->d_iters, Bp * sizeof(int32_t)},
-        {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)}};
+        {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)},
+        {(void **)&s->d_wl, (Bp + 2) * sizeof(int)}};
     for (auto &x : a) {
         HIP_TRY(s, hipMalloc(x.p, x.n));
         s->ws_bytes += x.n;
     }
+    HIP_TRY(s, hipMemset(s->d_wl, 0, (Bp + 2) * sizeof(int)));
     if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
         CondWork<double> cw;
         const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
@@ -258,6 +300,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     }
     if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -287,7 +330,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -369,6 +412,39 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         const size_t lds = (size_t)4 * TEAM_LDS * sizeof(T);
         constexpr bool F64 = sizeof(T) == 8;
         const bool mf = F64 && s->team_mfma;
+        // Default FP64 path: the active-set kernel makes the first attempt of every instance; the general kernel
+        // runs on the work list of what that attempt could not settle.  Taken when the single-kernel path would
+        // start with an active-set attempt as well (polish on, first attempt before any interior-point iteration).
+        const bool split = mf && fused && s->team_split && s->cfg.qp_polish && s->cfg.qp_polish_budget > 0 &&
+                           s->cfg.qp_polish_passes > 0 && s->cfg.qp_polish_mu >= s->cfg.qp_mu0 &&
+                           s->cfg.sim_num_steps <= AS_MAX_STEPS && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
+        if constexpr (F64) {
+            if (split) {
+                WorkList wl;
+                wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
+                const size_t lds_as = (size_t)4 * (c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE) * sizeof(double);
+                const int nlist = std::min((B + 3) / 4, 128);
+                const bool traj = x_out != nullptr || u_out != nullptr;
+                int occ_as = s->team_occ;
+                // two waves per SIMD need >= 2048 waves; the per-stage variant spills inside its sweeps at 256 registers
+                // (measured slower than one wave per SIMD at every batch size), so only the shared variant takes it
+                if (occ_as == 0) occ_as = (c.shared && (B + tpw - 1) / tpw >= 2048) ? 2 : 1;
+#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw); \
+                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw); } while (0)
+                if (c.shared) {
+                    if (traj) NMPC_LAUNCH_AS(true, true); else NMPC_LAUNCH_AS(true, false);
+                    hipLaunchKernelGGL(k_team_ipm_list<true>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+                } else {
+                    if (traj) NMPC_LAUNCH_AS(false, true); else NMPC_LAUNCH_AS(false, false);
+                    hipLaunchKernelGGL(k_team_ipm_list<false>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+                }
+#undef NMPC_LAUNCH_AS
+                HIP_TRY(s, hipGetLastError());
+                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
+                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true;
+                return 0;
+            }
+        }
 #define NMPC_LAUNCH_TEAM(W_, SH_, MF_) hipLaunchKernelGGL((k_team_ipm<T, W_, SH_, MF_>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw)
         if (mf) {
             if (occ == 1 && c.shared) NMPC_LAUNCH_TEAM(1, true, F64);
@@ -724,6 +800,7 @@ int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, 
 }
 
 const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : nullptr; }
+const int32_t *nmpc_device_passes(nmpc_solver *s) { return s ? s->d_npol : nullptr; }
 
 #ifdef NMPC_PROFILE
 // diagnostic builds only (tools/profile_sweeps.py): int64 [8][Bp] DEVICE pointer and its row stride

@@ -181,8 +181,11 @@ struct Pair {
 template <class T, bool BATCH, bool SHARED, bool MF>
 __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
                                          const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0,
-                                         bool lds_prefilled = false)
+                                         bool lds_prefilled = false, int inst_ov = -2, bool resume = false)
 {
+    // inst_ov != -2: the instance of this team comes from a work list (k_team_ipm_list; < 0 = idle team)
+    // resume: the first active-set attempt of the instance has been made - and given up - by the active-set
+    // kernel (nmpc_team_as.hpp): continue exactly where the single-kernel path would be after that attempt
     // lane -> (team, row): team b owns lanes {16a + 4b + c}, row r = 4a + c.  This is the block layout of
     // v_mfma_f64_4x4x4_4b_f64 (operand/result element (a,c) of block b sits in lane 16a + 4b + c, probed
     // with tools/probe_mfma), so a 4x4 tile of a team's matrices is one register across the team.
@@ -194,8 +197,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     const int rr = r < NX ? r : NX - 1;   // row used for loads; rows 13..15 shadow row 12 and never store
     const int j = r & 3;                  // input component handled by lanes r < 4 (others shadow)
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * tpw + team;   // 1, 2 or 4 live teams per wave (launch decides)
-    const bool valid = team < tpw && inst < B;
+    int inst = inst_ov != -2 ? inst_ov : blockIdx.x * tpw + team;   // 1, 2 or 4 live teams per wave (launch decides)
+    const bool valid = inst_ov != -2 ? (inst >= 0 && inst < B) : (team < tpw && inst < B);
     if (!valid) inst = B - 1;             // idle teams shadow the last instance and never store
     const int N = c.N;
     const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
@@ -322,6 +325,10 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
     NMPC_PROF_SINCE(t_entry)
     T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu;
     int it = 0, status = 0, npol = 0, pass_in_attempt = 0;
+    if (resume) {                 // one failed attempt behind us: its passes count, the next one waits for mu <= 1e-2 polish_mu
+        npol = w.npol[inst] < 0 ? -w.npol[inst] : w.npol[inst];
+        pol_mu *= T(1e-2);
+    }
     int k_top = N - 1;      // highest stage this team's next backward sweep has to refactorise
     bool maybe_pins = false; // the current pin set may be non-empty (decides what the forward sweep prefetches)
     int ck_valid = 0;        // checkpoints 1..ck_valid of this team are current
@@ -1613,15 +1620,15 @@ __device__ __forceinline__ void vde_col_rt(const Consts<T> &c, const Jac<T> &J, 
 
 template <class T>
 __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B, int tpw,
-                                             T *smem = nullptr)
+                                             T *smem = nullptr, int inst_ov = -2)
 {
     // smem != null (fused launch) and a shared cold-start linearisation: the stage matrices go straight
     // into the team's LDS arrays (natural layout, as load_stage leaves them) and never touch HBM
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
     const int rr = r < NX ? r : NX - 1, j = r & 3;
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * tpw + team;
-    const bool valid = team < tpw && inst < B;
+    int inst = inst_ov != -2 ? inst_ov : blockIdx.x * tpw + team;
+    const bool valid = inst_ov != -2 ? (inst >= 0 && inst < B) : (team < tpw && inst < B);
     if (!valid) inst = B - 1;
     const int N = c.N;
     const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;

@@ -1,0 +1,663 @@
+// nmpc_team_as.hpp -- the active-set kernel of the default FP64 path (gfx950 device code).
+//
+// What it is: preparation (RTI linearisation, controller.py:419-445 staging) + the FIRST active-set attempt of
+// the QP (up to qp_polish_passes passes of "pin the active bounds, solve the remaining LQ problem with one
+// Riccati factorisation + forward sweep, check the KKT conditions of the QP in the same sweep") for four
+// instances per wave -- the tile-form sweeps of nmpc_team.hpp (v_mfma_f64_4x4x4 register tiles, lane
+// (a,c) of team b = lane 16a + 4b + c) and nothing else.  On the near-hover set 99.3 % of the instances are
+// accepted after the first pass and all of them within three; only what this attempt cannot settle (a
+// failed factorisation, a pass budget that runs out) is appended to a work list, which the general kernel
+// k_team_ipm_list (interior-point iteration + later active-set attempts) drains in a second launch.
+//
+// Why a kernel of its own: the general kernel holds prepare + active set + all interior-point
+// sweeps live at once -- 449 registers, 291 scalar spills, one wave per SIMD -- although its interior-point
+// half never runs on the headline workload.  This kernel carries no interior-point state, takes its
+// per-lane constants into vector registers once (the 200-dword constant block is not touched inside a
+// sweep), stages nothing it can form on the fly (the cost gradients come straight from yref / x_init: no
+// qr array, no xl / ul copy) and needs 10 KB of LDS per wave, so two waves fit a SIMD.
+//
+// Arithmetic: identical to the tile-form sweeps A and B of team_ipm (same products, same order), so the
+// pass statistics and the accepted solutions are the same to rounding; the oracle restates the algorithm
+// (oracle/nmpc_oracle.c, active-set polish) and the GPU parity tests hold 1e-9 against it.
+//
+// Linearisation: the state of a shooting interval is integrated by ONE lane (lane r of a team takes stage
+// k0 + r of a chunk of AS_CH stages: 4 model evaluations per stage instead of 4 replicated in 16 lanes),
+// which leaves the points at which the model Jacobian is needed -- q, omega at the start and at the
+// midpoint of every ERK step -- in LDS; the forward sensitivities are then propagated per stage in tile form
+// (12 MFMAs per variational-equation evaluation, Jacobian tiles from per-lane coefficient patterns).
+#pragma once
+
+#include <type_traits>
+
+#include "nmpc_ipm.hpp"
+#include "nmpc_team.hpp"
+
+namespace nmpc {
+
+constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
+constexpr int AS_EV = 32;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2
+constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
+// LDS carve per team, in doubles
+constexpr int A_AD = 0;              // [16][8]  rows of the dense A columns (natural layout)
+constexpr int A_B = A_AD + 128;      // [16][4]
+constexpr int A_BV = A_B + 64;       // [16]
+constexpr int A_HG = A_BV + 16;      // [16]     Huu (10) | gu (4)
+constexpr int A_D = A_HG + 16;       // [16]     D | rhat | free mask | pinned value
+constexpr int A_H = A_D + 16;        // [16]     stage gradient, natural rows
+constexpr int A_XH = A_H + 16;       // [16]
+constexpr int A_RED = A_XH + 16;     // [32]     small reductions
+constexpr int A_EV = A_RED + 40;     // evaluation points of the linearisation
+// team strides 2752 B / 4544 B = 192 B past a multiple of the 256-B bank row (see TEAM_LDS in nmpc_team.hpp)
+constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 344
+constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 568
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// transposed Jacobian tiles at an evaluation point given as (q, omega, t2 = 2 (sum u) / m)
+__device__ __forceinline__ void jac_tiles_ev(double inv_mass, const JacCoef<double> &k, const double *e, double t2, int ta,
+                                             double &FvqT, double &FqqT, double &FqwT, double &FwwT, double &r3a)
+{
+    const double qw = e[0], qx = e[1], qy = e[2], qz = e[3], wx = e[4], wy = e[5], wz = e[6];
+    FvqT = t2 * (k.vq[0] * qw + k.vq[1] * qx + k.vq[2] * qy + k.vq[3] * qz);
+    FqqT = k.qq[0] * wx + k.qq[1] * wy + k.qq[2] * wz;
+    FqwT = k.qw[0] * qw + k.qw[1] * qx + k.qw[2] * qy + k.qw[3] * qz;
+    FwwT = k.ww[0] * wx + k.ww[1] * wy + k.ww[2] * wz;
+    const double r0 = 2.0 * (qx * qz + qw * qy) * inv_mass, r1 = 2.0 * (qy * qz - qw * qx) * inv_mass,
+                 r2 = (1.0 - 2.0 * (qx * qx + qy * qy)) * inv_mass;
+    r3a = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : 0.0));
+}
+
+// work list of the instances the active-set kernel hands to the general kernel
+struct WorkList {
+    int *count;     // [1] entries appended by this launch (zero on entry; reset by the consumer)
+    int *done;      // [1] consumer workgroups finished (the last one resets both)
+    int *list;      // [Bp] instance indices
+};
+
+template <bool SHARED, bool TRAJ>
+__device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<double> &in,
+                                        const Outputs<double> &out, const TeamWork<double> &tw, const WorkList &wl,
+                                        int B, int tpw, double *smem)
+{
+    // SHARED: cold start with one linearisation for all stages (x_k = x0, u_k = 0 folded at compile time)
+    // TRAJ:   the caller wants x_out / u_out: the forward sweep also leaves xhat_k and every candidate input
+    using T = double;
+    using NoPins = std::integral_constant<bool, false>;
+    using WithPins = std::integral_constant<bool, true>;
+    constexpr int LDS_T = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    NMPC_PROF_BEGIN
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
+    const int ta = r >> 2, tc = r & 3, j = tc;
+    const int rr = r < NX ? r : NX - 1;
+    const bool rowl = r < NX, cmpl = r < NU;
+    int inst = blockIdx.x * tpw + team;
+    const bool valid = team < tpw && inst < B;
+    if (!valid) inst = B - 1;             // idle teams read the inputs of the last instance ...
+    const int winst = valid ? inst : w.Bp;   // ... and work in a spare workspace row, so that no store of a sweep is predicated
+    const int lane = inst;                // profiling slot (NMPC_PROFILE builds)
+    (void)lane;
+    const int N = c.N;
+    T *S = smem + team * LDS_T;
+    T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sD = S + A_D, *sh = S + A_H, *sXh = S + A_XH;
+    T *sRed = S + A_RED, *sEv = S + A_EV;
+    const bool warm = !SHARED && in.x_init != nullptr && in.u_init != nullptr;
+    const T *x0p = in.x0 + (size_t)inst * NX;
+    const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
+    const T *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
+    const T *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : x0p;
+    const T *ui = warm ? in.u_init + (size_t)inst * N * NU : x0p;
+    T *const tLM_own = tw.tLM + (size_t)winst * N * TLM_ROWS, *const tIV_own = tw.tIV + (size_t)winst * N * IV_ROWS;
+    const int ckpt = c.polish_ckpt;
+    T *const tP_own = tw.tP ? tw.tP + (size_t)winst * (ckpt + 1) * TP_ROWS : nullptr;
+    T *tAB = SHARED ? nullptr : w.tAB + (size_t)winst * N * TAB_ROWS;
+    // a team that has finished keeps sweeping with its wave (the MFMAs are wave-wide) but must not touch its
+    // accepted results: from then on it works in the spare row too (pointers switched once per pass)
+    T *const tLM_spare = tw.tLM + (size_t)w.Bp * N * TLM_ROWS, *const tIV_spare = tw.tIV + (size_t)w.Bp * N * IV_ROWS;
+    T *const tP_spare = tw.tP ? tw.tP + (size_t)w.Bp * (ckpt + 1) * TP_ROWS : nullptr;
+    T *tLM = tLM_own, *tIV = tIV_own, *tP = tP_own;
+
+    int natR[4], natC[4];
+    NMPC_UNROLL for (int t = 0; t < 4; t++) { natR[t] = nat_of(t, ta); natC[t] = nat_of(t, tc); }
+    // ---- per-lane constants, taken into vector registers once
+    T dt_v = c.dt, kkt_v = c.kkt_tol;
+    asm volatile("" : "+v"(dt_v), "+v"(kkt_v));
+    const T x0r = x0p[rr];
+    const T Wq_r = pick13(c.Wq, rr), WqN_r = pick13(c.WqN, rr);
+    const T Wr_j = sel4(c.Wr, j), Wr_a = sel4(c.Wr, ta);
+    const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
+    const T lb_a = sel4(c.lbu, ta), ub_a = sel4(c.ubu, ta), Rd_a = sel4(c.Rd, ta);
+    T Qdg[4];                              // diagonal of the stage Hessian in tile layout
+    NMPC_UNROLL for (int t = 0; t < 4; t++) Qdg[t] = (ta == tc && natR[t] >= 0) ? pick13(c.Qd, natR[t]) : T(0);
+    const int polish_passes = c.polish_passes;
+    const T Idt = (ta == tc) ? T(1) : T(0);
+    const T HuuD = (ta == tc) ? Rd_a : T(0);          // diagonal of Huu without pins
+    NMPC_STAMP(2)
+
+    // =========================== preparation: linearise Ns shooting intervals
+    {
+        const int Ns = SHARED ? 1 : N;
+        JacCoef<T> jk;
+        jac_coef(c, r, jk);
+        const T hh = T(0.5) * c.h, hstep = c.h, inv_mass = c.inv_mass;
+        const int nsteps = c.steps;
+        constexpr int CH = SHARED ? 1 : AS_CH;
+        for (int k0 = 0; k0 < Ns; k0 += CH) {
+            // ---- phase A: lane r < CH integrates the state of stage k0 + r and leaves the evaluation points
+            {
+                const int k = k0 + r;
+                const bool mine = r < CH && k < Ns;
+                const int kk = mine ? k : 0;
+                T xs[NX], us[NU], xn1[NX];
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (warm && kk > 0) ? xi[(size_t)kk * NX + i] : x0p[i];   // stage 0 is pinned to x0
+                NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = warm ? ui[(size_t)kk * NU + i] : T(0);
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xn1[i] = warm ? xi[(size_t)(kk + 1) * NX + i] : x0p[i];
+                T *ev = sEv + (SHARED ? 0 : (r < CH ? r : 0) * AS_EV);
+                for (int st = 0; st < nsteps; st++) {
+                    T f1[NX], xm[NX], f2[NX];
+                    model_f(c, xs, us, f1);
+                    NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + hh * f1[i];
+                    if (mine) {
+                        NMPC_UNROLL for (int i = 0; i < 7; i++) { ev[st * 14 + i] = xs[6 + i]; ev[st * 14 + 7 + i] = xm[6 + i]; }
+                    }
+                    model_f(c, xm, us, f2);
+                    NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += hstep * f2[i];
+                }
+                if (mine) {
+                    ev[28] = T(2) * (us[0] + us[1] + us[2] + us[3]) * inv_mass;
+                    if (SHARED) {
+                        NMPC_UNROLL for (int i = 0; i < NX; i++) sbv[i] = xs[i] - xn1[i];
+                    } else {
+                        T *a = tAB + (size_t)k * TAB_ROWS + 156;
+                        NMPC_UNROLL for (int i = 0; i < NX; i++) a[i] = xs[i] - xn1[i];
+                    }
+                }
+            }
+            NMPC_WSYNC();
+            NMPC_STAMP(3)
+            // ---- phase B: forward sensitivities of every stage of the chunk, tile form
+            for (int e = 0; e < CH; e++) {
+                const int k = k0 + e;
+                if (k >= Ns) break;
+                const T *ev = sEv + e * AS_EV;
+                const T t2 = ev[28];
+                T Sx[4][3];
+                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                    NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[rt][ct] = 0;
+                }
+                Sx[2][0] = (ta == tc) ? T(1) : T(0);                  // d q / d q = I
+                Sx[3][1] = (ta == tc && ta < 3) ? T(1) : T(0);        // d w / d w = I
+                for (int st = 0; st < nsteps; st++) {
+                    T K[4][3], Sm[4][3];
+                    T a1, a2, a3, a4, a5;
+                    jac_tiles_ev(inv_mass, jk, ev + st * 14, t2, ta, a1, a2, a3, a4, a5);
+                    vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx, K);
+                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                        NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[rt][ct] = Sx[rt][ct] + hh * K[rt][ct];
+                    }
+                    jac_tiles_ev(inv_mass, jk, ev + st * 14 + 7, t2, ta, a1, a2, a3, a4, a5);
+                    vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm, K);
+                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                        NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[rt][ct] += hstep * K[rt][ct];
+                    }
+                }
+                {                             // natural layout: Ad rows [13][8] | B rows [13][4] (b came from phase A)
+                    T *a = SHARED ? S : tAB + (size_t)k * TAB_ROWS;
+                    const int oA = SHARED ? A_AD : 0, oB = SHARED ? A_B : 104;
+                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                        if (natR[rt] >= 0) {
+                            a[oA + natR[rt] * 8 + tc] = Sx[rt][0];
+                            a[oA + natR[rt] * 8 + 4 + tc] = tc < 3 ? Sx[rt][1] : T(0);
+                            a[oB + natR[rt] * NU + tc] = Sx[rt][2];
+                        }
+                    }
+                }
+            }
+            NMPC_WSYNC();
+            NMPC_STAMP(4)
+        }
+    }
+    __syncthreads();          // stage matrices (LDS, or this wave's own global rows) visible to every lane
+    NMPC_STAMP(7)
+
+    // stage matrices of the per-stage variant: global -> registers one stage ahead -> LDS -> tiles
+    T pfs[13];
+    auto fetch_stage = [&](int k) {
+        const T *a = tAB + (size_t)k * TAB_ROWS;
+        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) pfs[cc] = a[rr * 8 + cc];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) pfs[8 + i] = a[104 + rr * NU + i];
+        pfs[12] = a[156 + rr];
+    };
+    auto put_stage = [&]() {
+        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) sAd[r * 8 + cc] = pfs[cc];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) sB[r * 4 + i] = pfs[8 + i];
+        sbv[r] = pfs[12];
+        NMPC_WSYNC();
+    };
+    // linearisation point of stage k, natural row rr / input comp (cold start: x_k = x0, u_k = 0)
+    auto xlin = [&](int k) -> T { return (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r; };
+    auto ulin = [&](int k, int comp) -> T { return warm ? ui[(size_t)k * NU + comp] : T(0); };
+
+    int status = 0, npol = 0, pass_in_attempt = 0;
+    int k_top = N - 1;       // highest stage this team's next backward sweep has to refactorise
+    int ck_valid = 0;        // checkpoints 1..ck_valid of this team are current
+    enum { M_POL = 1, M_DONE = 2, M_GIVEUP = 3 };
+    int mode = valid ? M_POL : M_DONE;
+    int pass = 0;            // wave-uniform pass counter: all live teams of a wave are in the same pass
+    T u0_cand = 0;           // lane (a,0): candidate command of input a from the latest forward sweep
+    // lanes of this team in a wave-wide ballot
+    const unsigned long long team_mask = 0x000F000F000F000Full << (4 * team);
+
+    for (;;) {
+        if (__ballot(mode == M_POL) == 0) break;
+        const bool pol = mode == M_POL;
+        tLM = pol ? tLM_own : tLM_spare; tIV = pol ? tIV_own : tIV_spare; tP = pol ? tP_own : tP_spare;
+        // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
+        int ks = N - 1;
+        if (tP && pass > 0) {
+            if (r == 0) { sRed[28] = (T)(pol ? k_top : -1); sRed[29] = (T)(pol ? ck_valid : N); }
+            __syncthreads();
+            ks = 0;
+            int vmin = N;            // every live team must own the checkpoint the wave resumes from
+            for (int t = 0; t < 4; t++) {
+                const int kt = (int)smem[t * LDS_T + A_RED + 28], vt = (int)smem[t * LDS_T + A_RED + 29];
+                ks = kt > ks ? kt : ks;
+                vmin = vt < vmin ? vt : vmin;
+            }
+            if (ks >= vmin) ks = N - 1;
+            ks = __builtin_amdgcn_readfirstlane(ks);
+        }
+        // checkpoint window of this pass (see team_ipm): two stages in the first pass, the configured window after
+        const int wnd = pass_in_attempt == 0 ? (ckpt < 2 ? ckpt : 2) : ckpt;
+        if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
+
+        // ================= sweep A: backward factorisation in tile form.
+        // Same products as the tile form of sweep A in team_ipm.  What differs is the shape of the code: a stage is
+        // ONE basic block (no predicated store: finished and idle teams work in a spare workspace row), P B and
+        // B'P B come first so that the 4x4 Cholesky - a serial chain of ~90
+        // vector instructions - runs beside the ~60 MFMAs that do not depend on it, and the first pass (nothing
+        // pinned, by construction) is compiled without any of the pin handling.
+        bool ok = true, nanp = false;
+        auto sweepA = [&](auto pins_tag) {
+            constexpr bool PINS = decltype(pins_tag)::value;
+            T Aq0[4], Aq1b[4], Bt[4];
+            auto load_tiles = [&]() {
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    const int l = natR[kt] >= 0 ? natR[kt] : 0;
+                    const bool real = natR[kt] >= 0;
+                    const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc], bv_ = sbv[l];
+                    Aq0[kt] = real ? a0 : T(0);
+                    Aq1b[kt] = real ? (tc < 3 ? a1 : bv_) : ((kt == 3 && ta == 3 && tc == 3) ? T(1) : T(0));
+                    Bt[kt] = real ? bb : T(0);
+                }
+            };
+            if (SHARED) load_tiles(); else fetch_stage(ks);
+            T Pt[4][4];
+            if (ks == N - 1) {
+                // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
+                sh[r] = WqN_r * (xlin(N) - ye[rr]);
+                NMPC_WSYNC();
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                        T v = (it == jt && ta == tc && natR[it] >= 0) ? pick13(c.QdN, natR[it]) : T(0);
+                        const T qa = sh[natR[it] >= 0 ? natR[it] : 0], qb = sh[natC[jt] >= 0 ? natC[jt] : 0];
+                        if (jt == 3 && tc == 3 && natR[it] >= 0) v = qa;
+                        if (it == 3 && ta == 3 && natC[jt] >= 0) v = qb;
+                        Pt[it][jt] = v;
+                    }
+                }
+                NMPC_WSYNC();
+            } else {                  // resume from the checkpoint an earlier pass left
+                const T *cp = tP + (size_t)(ks + 1) * TP_ROWS + r;
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
+                }
+            }
+            // scalars of a stage are fetched one stage ahead (global loads stay in flight over the stage):
+            // reference row rr, reference / linearisation input of component j (pins) or a (no pins), pin code
+            const int cu = PINS ? j : ta;
+            T n_yx = yr[(size_t)ks * NY + rr], n_yu = yr[(size_t)ks * NY + NX + cu];
+            T n_xl = xlin(ks), n_ul = ulin(ks, cu);
+            T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
+            auto stage = [&](int k, auto last_tag) {
+                constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
+                if (!SHARED) { put_stage(); if (!LAST) fetch_stage(k - 1); load_tiles(); }
+                T *lmk = tLM + k * TLM_ROWS;
+                const T ul = n_ul, pc = n_pc;
+                // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
+                // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
+                // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
+                // (found by the permutation test at N = 600)
+                T rk = (PINS ? Wr_j : Wr_a) * (ul - n_yu);
+                const T q_r = Wq_r * (n_xl - n_yx);
+                asm volatile("" : "+v"(rk));             // (q_r passes through LDS, which rounds it in both variants)
+                if (!LAST) {
+                    n_yx = yr[(size_t)(k - 1) * NY + rr]; n_yu = yr[(size_t)(k - 1) * NY + NX + cu];
+                    n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
+                    if (PINS) n_pc = tIV[(k - 1) * IV_ROWS + 16 + j];
+                }
+                T mask_a = T(1), mask_c = T(1), D_a = Rd_a, rhat_a = rk;
+                bool any_pins = false;
+                T Aq1[4];
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
+                if (!LAST) sh[r] = q_r;                  // natural row rr of the stage gradient
+                if (PINS) {
+                    // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps
+                    // R_jj so that u_j = bound
+                    const T lo = lbj - ul, hi = ubj - ul;
+                    const bool pinned = pol && pc != T(0);
+                    const T vpin = pc < T(0) ? lo : hi;
+                    if (cmpl) {
+                        sD[j] = Rdj;
+                        sD[4 + j] = pinned ? -Rdj * vpin : rk;
+                        sD[8 + j] = pinned ? T(0) : T(1);
+                        sD[12 + j] = pinned ? vpin : T(0);
+                    }
+                    NMPC_WSYNC();
+                    mask_a = sD[8 + ta]; mask_c = sD[8 + tc]; D_a = sD[ta]; rhat_a = sD[4 + ta];
+                    any_pins = __ballot(pinned) != 0;
+                    if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
+                        const T vp = sD[12 + tc];
+                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                            const T sm = quad_sum(Bt[kt] * vp);
+                            if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
+                        }
+                    }
+                }
+                // P B and Hr = B'PB first: the Cholesky below depends on nothing else
+                T WB[4], Hr = 0;
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    T aB = 0;
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
+                    WB[it] = aB;
+                }
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
+                const T Huu = (PINS ? ((ta == tc) ? D_a : T(0)) : HuuD) + (PINS ? mask_a * mask_c * Hr : Hr);
+                if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
+                NMPC_WSYNC();
+                T Lf[10];
+                NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
+                // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt))
+                T W0[4], W1[4];
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    T a0 = 0, a1 = 0;
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                        a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                        a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
+                    }
+                    W0[it] = a0; W1[it] = a1;
+                }
+                T PA[4][4];
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    PA[kt][0] = Pt[kt][0];
+                    PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
+                    PA[kt][2] = W0[kt];
+                    PA[kt][3] = W1[kt];
+                }
+                // X = B'(Pbar Abar) (column 15: B'h)
+                T X0raw = 0;
+                T X[4];
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    T a = 0;
+                    if (jt == 0) a = mfma44(WB[0], Idt, T(0));
+                    else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
+                    else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
+                    if (jt == 0) X0raw = a;
+                    X[jt] = PINS ? mask_a * a : a;
+                    // gradient rows of the pinned inputs for the multiplier check of the forward sweep
+                    if (PINS) { if (any_pins) lmk[TLM_G + jt * 16 + tc * 4 + ta] = a; }
+                }
+                if (PINS) { if (any_pins) lmk[TLM_G + 64 + tc * 4 + ta] = Hr; }
+                if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
+                // the (q,w) x (q,w) tiles of Abar'(Pbar Abar) and the (p,v) rows: independent of the Cholesky
+                T Pn[4][4];
+                if (!LAST) {
+                    T qcol[4], qrow[4];
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+                        const T qa = sh[natR[t] >= 0 ? natR[t] : 0], qb = sh[natC[t] >= 0 ? natC[t] : 0];
+                        qcol[t] = (tc == 3 && natR[t] >= 0) ? qa : T(0);
+                        qrow[t] = (ta == 3 && natC[t] >= 0) ? qb : T(0);
+                    }
+                    // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                        T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
+                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
+                        if (jt >= 2) {
+                            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                                a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                                a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                            }
+                        }
+                        Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
+                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0));
+                        Pn[2][jt] = a2;
+                        Pn[3][jt] = a3;
+                    }
+                    NMPC_UNROLL for (int it = 2; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
+                    }
+                }
+                // Cholesky (replicated in every lane of the team)
+                NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
+                    T d = Lf[lidx(jj, jj)];
+                    NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
+                    const bool pos = d > T(0);
+                    ok &= pos; nanp |= !(d == d); d = pos ? d : T(1);
+                    const T rd = fast_rsqrt(d);
+                    Lf[lidx(jj, jj)] = rd;
+                    NMPC_UNROLL for (int i = jj + 1; i < NU; i++) {
+                        T a = Lf[lidx(i, jj)];
+                        NMPC_UNROLL for (int l = 0; l < jj; l++) a -= Lf[lidx(i, l)] * Lf[lidx(jj, l)];
+                        Lf[lidx(i, jj)] = a * rd;
+                    }
+                }
+                // Y = L^-T as a tile (lane (a,c) holds (L^-1 e_a)_c), M = L^-1 X = Y' X
+                T ea[NU];
+                NMPC_UNROLL for (int i = 0; i < NU; i++) ea[i] = (i == ta) ? T(1) : T(0);
+                l_solve(Lf, ea);
+                const T Y = sel4(ea, tc);
+                T M[4];
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    M[jt] = mfma44(Y, X[jt], T(0));
+                    lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];              // where the forward sweep reads it transposed
+                }
+                lmk[TLM_Z + r] = mfma44(Y, Idt, T(0));                        // Y' = L^-1 as a tile
+                if (!LAST) {
+                    T Mn[4];
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M[t];
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+                    }
+                    if (tP && k <= wnd) {
+                        T *cp = tP + (size_t)k * TP_ROWS + r;
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
+                        }
+                    }
+                }
+                NMPC_WSYNC();
+            };
+            for (int k = ks; k > 0; k--) stage(k, std::integral_constant<bool, false>{});
+            stage(0, std::integral_constant<bool, true>{});
+        };
+        if (pass == 0) sweepA(NoPins{}); else sweepA(WithPins{});
+        NMPC_STAMP(0)
+        __syncthreads();
+        bool pol_fail = false;
+        if (pol && !ok) {
+            if (nanp) { status = 1; mode = M_DONE; }
+            else pol_fail = true;                       // give up this attempt
+        }
+        const bool pol2 = mode == M_POL;
+
+        // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
+        // is one basic block; operands arrive two stages ahead in two alternating register sets
+        bool viol = false, heavy = false;
+        int kchgB = -1;           // highest stage whose pin set this pass changes
+        T xh = 0;
+        auto sweepB = [&](auto pins_tag) {
+            constexpr bool PINS = decltype(pins_tag)::value;
+            T AT2[4], AT3[4], BT[4];
+            auto load_tiles_T = [&]() {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    const int l = natC[it] >= 0 ? natC[it] : 0;
+                    const bool real = natC[it] >= 0;
+                    const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta], bv_ = sbv[l];
+                    AT2[it] = real ? a2 : T(0);
+                    AT3[it] = real ? (ta < 3 ? a3 : bv_) : ((it == 3 && tc == 3 && ta == 3) ? T(1) : T(0));
+                    BT[it] = real ? bb : T(0);
+                }
+            };
+            if (SHARED) load_tiles_T(); else fetch_stage(0);
+            T xt[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+            // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
+            int xslot[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
+            const int cslot = tc == 0 ? 12 + ta : 0, pslot = tc == 0 ? 16 + ta : 0;
+            struct Ops { T mt[4], z, ul, pc; };
+            auto fetch_ops = [&](int kq, Ops &o) {
+                const int k = kq < N ? kq : N - 1;
+                const T *lmn = tLM + k * TLM_ROWS;
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
+                o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+                o.ul = ulin(k, ta);
+                o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
+            };
+            auto stageB = [&](int k, const Ops &o) {
+                if (!SHARED) { put_stage(); if (k + 1 < N) fetch_stage(k + 1); load_tiles_T(); }
+                T *ivk = tIV + k * IV_ROWS;
+                const T ul = o.ul, pc = o.pc;
+                if (TRAJ) {                    // xhat_k for the output sweep
+                    T *xs = tLM + k * TLM_ROWS + 66;
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
+                }
+                T xn[4];
+                xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
+                          + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
+                const T ut = -mfma44(o.z, v, T(0));                           // lane (a,0): u_a
+                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+                // KKT check of the pass, input a in lane (a,0): a free input must sit inside its box; a pinned one
+                // must have a multiplier of the right sign (gradient from the rows the factor sweep left)
+                const T uj = ut;
+                const T lo = lb_a - ul, hi = ub_a - ul;
+                const T tolb = kkt_v * (T(1) + fabs(lo) + fabs(hi));
+                T npc = uj < lo - tolb ? T(-1) : (uj > hi + tolb ? T(1) : T(0));
+                T ue = uj;
+                bool nanq = !(uj == uj);
+                if (PINS) {
+                    const bool pin_here = pol2 && pc != T(0);
+                    const T vpin = pc < T(0) ? lo : hi;
+                    ue = pin_here ? vpin : uj;                                 // pinned inputs sit exactly on the bound
+                    if (__ballot(tc == 0 && pin_here) != 0) {
+                        const T *lmn = tLM + k * TLM_ROWS;
+                        T cG[5];
+                        NMPC_UNROLL for (int g5 = 0; g5 < 5; g5++) cG[g5] = lmn[TLM_G + g5 * 16 + r];
+                        T rka = Wr_a * (ul - yr[(size_t)k * NY + NX + ta]);
+                        asm volatile("" : "+v"(rka));
+                        const T uf = (tc == 0 && !pin_here) ? ue : T(0);                    // mask u
+                        T g = mfma44(cG[4], uf, T(0));
+                        T g2 = mfma44(cG[1], xt[1], mfma44(cG[0], xt[0], T(0)));
+                        g = mfma44(cG[3], xt[3], mfma44(cG[2], xt[2], g));
+                        g += g2 + Rd_a * ue + rka;
+                        const T tolg = kkt_v * (T(1) + fabs(g));
+                        const bool wrong = (pc < T(0) && g < -tolg) || (pc > T(0) && g > tolg);
+                        npc = pin_here ? (wrong ? T(0) : pc) : npc;
+                        nanq |= !(g == g);
+                    }
+                }
+                if (TRAJ) ivk[cslot] = ue;                                     // every candidate input
+                ivk[pslot] = npc;
+                if (k == 0) u0_cand = pol2 ? ue : u0_cand;
+                heavy |= nanq;
+                viol |= npc != pc;
+                kchgB = (npc != pc) ? k : kchgB;                               // ascending k: the last one is the highest
+                NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
+            };
+            Ops oa[2], ob[2];
+            fetch_ops(0, oa[0]); fetch_ops(1, oa[1]);
+            for (int k0 = 0; k0 < N; k0 += 4) {
+                fetch_ops(k0 + 2, ob[0]); fetch_ops(k0 + 3, ob[1]);
+                stageB(k0, oa[0]);
+                if (k0 + 1 < N) stageB(k0 + 1, oa[1]);
+                fetch_ops(k0 + 4, oa[0]); fetch_ops(k0 + 5, oa[1]);
+                if (k0 + 2 < N) stageB(k0 + 2, ob[0]);
+                if (k0 + 3 < N) stageB(k0 + 3, ob[1]);
+            }
+            // back to one natural row per lane
+            if (tc == 0) {
+                NMPC_UNROLL for (int t = 0; t < 4; t++)
+                    if (natR[t] >= 0) sXh[natR[t]] = xt[t];
+            }
+            NMPC_WSYNC();
+            xh = sXh[rr];
+            if (tc == 0) sRed[28 + ta] = (T)kchgB;
+        };
+        if (pass == 0) sweepB(NoPins{}); else sweepB(WithPins{});
+        NMPC_STAMP(1)
+        if (TRAJ) { if (rowl) tLM[66 + rr] = xh; }      // xhat_N parks in the unused xhat_0 slot (output sweep)
+        __syncthreads();
+        // team-wide flags from wave-wide ballots (only lanes (a,0) carry inputs; every row of xhat_N is checked)
+        const bool t_viol = (__ballot(viol && tc == 0) & team_mask) != 0;
+        const bool t_heavy = (__ballot((heavy && tc == 0) || !(xh == xh)) & team_mask) != 0;
+        const int kc = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
+        if (pol2) {
+            npol++;
+            pass_in_attempt++;
+            const bool unclean = pol_fail || t_viol || t_heavy;
+            if (!unclean) mode = M_DONE;                  // the pass satisfies the KKT conditions of the QP: accepted
+            else if (pol_fail || t_heavy || pass_in_attempt >= polish_passes) mode = M_GIVEUP;
+            else k_top = kc < ck_valid ? kc : N - 1;
+        }
+        pass++;
+        __syncthreads();   // sRed / sXh are reused by the next pass
+    }
+
+    // ---- outputs.  Accepted: the forward sweep left the candidate inputs (and xhat_k), the full step (U1) is
+    // applied stage-parallel into the caller's arrays.  NaN (status 1): zeros and the cold-start point.
+    // Given up: the general kernel solves the instance from scratch and writes everything.
+    NMPC_STAMP(6)
+    NMPC_PROF_END(w)
+    tLM = tLM_own; tIV = tIV_own;
+    if (!valid) return;
+    if (mode == M_GIVEUP) {
+        if (r == 0) {
+            w.npol[inst] = -npol;                          // the general kernel resumes its pass budget from here
+            const int slot = atomicAdd(wl.count, 1);
+            wl.list[slot] = inst;
+        }
+        return;
+    }
+    const bool accepted = status == 0;
+    if (r == 0) {
+        if (out.status) out.status[inst] = status;
+        w.iters[inst] = 0; w.status[inst] = status; w.npol[inst] = accepted ? npol : -npol;
+    }
+    if (tc == 0) out.u0[(size_t)inst * NU + ta] = accepted ? ulin(0, ta) + u0_cand : T(0);   // controller.py:448-452
+    if (TRAJ) {
+        constexpr int CH = 8;
+        for (int k0 = 0; k0 <= N; k0 += CH) {
+            T uv[CH], ulv[CH], xlv[CH], xhv[CH];
+            NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
+                uv[i] = tIV[ku * IV_ROWS + 12 + j];
+                ulv[i] = ulin(ku, j);
+                xlv[i] = xlin(k);
+                xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot
+            }
+            NMPC_UNROLL for (int i = 0; i < CH; i++) {
+                const int k = k0 + i;
+                if (k <= N) {
+                    if (out.x_out && rowl)
+                        out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = accepted ? xlv[i] + (k > 0 ? xhv[i] : T(0)) : x0r;
+                    if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = accepted ? ulv[i] + uv[i] : T(0);
+                }
+            }
+        }
+    }
+}
+
+#endif  // device
+
+}  // namespace nmpc

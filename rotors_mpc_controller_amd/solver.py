@@ -152,6 +152,10 @@ class NmpcOcpSolver:
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 
+    def device_passes_ptr(self) -> int:
+        """int32 [B] on the device: active-set passes of the last solve (> 0: accepted active-set solution)."""
+        return int(self._lib.nmpc_device_passes(self._h) or 0)
+
     def set_timing(self, on: bool) -> None:
         """HIP events around the kernels of every solve (default on; stats() then reports kernel times)."""
         self._check(self._lib.nmpc_set_timing(self._h, int(bool(on))))

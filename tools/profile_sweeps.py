@@ -60,3 +60,7 @@ print(f"batch {B} dtype {a.dtype} share={not a.no_share}: kernel {st['ms_solve']
 print(f"per-wave total: mean {tot.mean():.1f} us, max {tot.max():.1f} us")
 for i, n in enumerate(names):
     print(f"  {n:16s} mean {per_wave[i].mean():9.1f} us  ({100 * per_wave[i].sum() / tot.sum():5.1f} %)")
+imax = int(tot.argmax())
+print(f"slowest wave {imax}: " + ", ".join(f"{n.split()[0]} {per_wave[i, imax]:.1f}" for i, n in enumerate(names) if per_wave[i, imax] > 0))
+srt = np.sort(tot)
+print("per-wave total percentiles (us): " + ", ".join(f"p{q} {srt[min(len(srt) - 1, int(q / 100 * len(srt)))]:.1f}" for q in (10, 50, 90, 99, 100)))
