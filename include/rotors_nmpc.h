@@ -107,6 +107,8 @@ typedef struct nmpc_stats {
     double polish_mean;        /* active-set passes per instance (team mapping), mean / max */
     int32_t polish_max;
     int32_t n_polished;        /* instances that finished with an accepted active-set solution */
+    int32_t n_tail;            /* instances the active-set kernel handed to the general kernel (default FP64 path) */
+    double ms_tail;            /* device time of that second launch (k_team_ipm_list); ms_solve is then the first launch alone */
 } nmpc_stats;
 
 typedef struct nmpc_solver nmpc_solver; /* opaque; owns all device memory */
@@ -207,6 +209,21 @@ int nmpc_hold_command_device(nmpc_solver *s, int B, const void *u0, const int32_
  * normalize_q != 0 renormalises the quaternion as controller.py:406-409 does on every tick          */
 int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next,
                            int normalize_q, void *hip_stream);
+
+/* adjoint sensitivities of the model (the CasADi-generated `expl_vde_adj` of controller.py:267-355, which
+ * acados compiles next to expl_vde_forw).  x [B][13], u [B][4], lam [B][13] -> out [B][17]:
+ *   continuous != 0:  ( f_x(x,u)' lam | f_u(x,u)' lam )          -- what expl_vde_adj evaluates
+ *   continuous == 0:  ( A' lam | B' lam ) of the shooting interval that starts at (x,u), by the reverse sweep through the
+ *                     ERK scheme of controller.py:183-188 (no A, B formed): the discrete adjoint of expl_vde_forw's result */
+int nmpc_adjoint_sensitivities_device(nmpc_solver *s, int B, const void *x, const void *u, const void *lam, void *out,
+                                      int continuous, void *hip_stream);
+
+/* stationarity / feasibility report of trajectories (e.g. the x_out / u_out of a solve) for the NLP of controller.py:175-264,
+ * one adjoint sweep per instance: res [B][3] = ( max |projected Lagrangian gradient w.r.t. the inputs|,
+ * max dynamics defect |phi(x_k,u_k) - x_{k+1}|, max input-bound violation ).  acados reports the same quantities as
+ * res_stat / res_eq / res_ineq of its SQP; after ONE real-time iteration they measure how far the step is from converged */
+int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void *u_traj, const void *yref, const void *yref_e,
+                           int yref_bcast, void *res, void *hip_stream);
 
 const char *nmpc_version(void);
 

@@ -63,6 +63,7 @@ class NmpcStats(C.Structure):
         ("iter_mean", C.c_double), ("n_status", C.c_int32 * 5),
         ("ms_prepare", C.c_double), ("ms_solve", C.c_double), ("workspace_bytes", C.c_uint64),
         ("polish_mean", C.c_double), ("polish_max", C.c_int32), ("n_polished", C.c_int32),
+        ("n_tail", C.c_int32), ("ms_tail", C.c_double),
     ]
 
 
@@ -71,7 +72,7 @@ EXPORTS = (
     "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_stats", "nmpc_set_timing",
     "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
-    "nmpc_hold_command_device",
+    "nmpc_hold_command_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device",
 )
 
 
@@ -164,6 +165,10 @@ def load() -> C.CDLL:
     lib.nmpc_plant_step_device.restype = C.c_int
     lib.nmpc_hold_command_device.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.nmpc_hold_command_device.restype = C.c_int
+    lib.nmpc_adjoint_sensitivities_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.nmpc_adjoint_sensitivities_device.restype = C.c_int
+    lib.nmpc_kkt_report_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]
+    lib.nmpc_kkt_report_device.restype = C.c_int
     lib.nmpc_version.argtypes = []
     lib.nmpc_version.restype = C.c_char_p
     _lib = lib

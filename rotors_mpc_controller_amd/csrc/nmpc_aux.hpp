@@ -128,4 +128,69 @@ __global__ void k_plant_step(Consts<T> c, int B, const T *__restrict__ x, const 
     NMPC_UNROLL for (int i = 0; i < NX; i++) xn[(size_t)b * NX + i] = xs[i];
 }
 
+// Adjoint sensitivities: model_adj / erk_adjoint live in nmpc_lane.hpp (host + device, so that the CPU build of the
+// kernel bodies tests them too); the two kernels below batch them.
+// out [B][17] = ( A' lam (13) | B' lam (4) ) of the interval that starts at (x, u); cont != 0: the continuous
+// right-hand side ( f_x' lam | f_u' lam ) instead (what expl_vde_adj returns)
+template <class T>
+__global__ void k_adjoint_sens(Consts<T> c, int B, const T *__restrict__ x, const T *__restrict__ u, const T *__restrict__ lam,
+                               T *__restrict__ out, int cont)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T xs[NX], us[NU], l[NX], gu[NU];
+    NMPC_UNROLL for (int i = 0; i < NX; i++) { xs[i] = x[(size_t)b * NX + i]; l[i] = lam[(size_t)b * NX + i]; }
+    NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = u[(size_t)b * NU + i];
+    if (cont) {
+        Jac<T> J;
+        T ax[NX];
+        model_jac(c, xs, us, J);
+        model_adj(c, J, l, ax, gu);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) l[i] = ax[i];
+    } else {
+        erk_adjoint<T, ADJ_MAX_STEPS>(c, xs, us, l, gu, nullptr);
+    }
+    NMPC_UNROLL for (int i = 0; i < NX; i++) out[(size_t)b * (NX + NU) + i] = l[i];
+    NMPC_UNROLL for (int i = 0; i < NU; i++) out[(size_t)b * (NX + NU) + NX + i] = gu[i];
+}
+
+// Stationarity / feasibility report of a trajectory (x [B][N+1][13], u [B][N][4]) for the NLP of controller.py:175-264,
+// by ONE adjoint sweep per instance (no A, B):  lam_N = W_e (x_N - yref_e);  k = N-1..0:  g_u = W_u (u_k - yref_u) + B_k' lam_{k+1},
+// lam_k = W_x (x_k - yref_x) + A_k' lam_{k+1}.  res [B][3] = ( max_k |projected g_u| with the input box, max_k |phi(x_k,u_k) - x_{k+1}|,
+// max_k bound violation ).  The projection: an input on its lower (upper) bound contributes only the negative (positive) part
+// of g_u.  It is what tells a converged SQP iterate from an RTI step that still has a way to go.
+template <class T>
+__global__ void k_kkt_report(Consts<T> c, int B, const T *__restrict__ x, const T *__restrict__ u, const T *__restrict__ yref,
+                             const T *__restrict__ yref_e, int yref_bcast, T *__restrict__ res)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const int N = c.N;
+    const T *xb = x + (size_t)b * (N + 1) * NX, *ub = u + (size_t)b * N * NU;
+    const T *yr = yref_bcast ? yref : yref + (size_t)b * N * NY, *ye = yref_bcast ? yref_e : yref_e + (size_t)b * NX;
+    T lam[NX];
+    NMPC_UNROLL for (int i = 0; i < NX; i++) lam[i] = c.WqN[i] * (xb[(size_t)N * NX + i] - ye[i]);
+    T rs = 0, rd = 0, rb = 0;
+    for (int k = N - 1; k >= 0; k--) {
+        T xs[NX], us[NU], gu[NU], xn[NX];
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = xb[(size_t)k * NX + i];
+        NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = ub[(size_t)k * NU + i];
+        erk_adjoint<T, ADJ_MAX_STEPS>(c, xs, us, lam, gu, xn);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) {
+            lam[i] += c.Wq[i] * (xs[i] - yr[(size_t)k * NY + i]);
+            rd = fmax(rd, fabs(xn[i] - xb[(size_t)(k + 1) * NX + i]));
+        }
+        NMPC_UNROLL for (int j = 0; j < NU; j++) {
+            const T g = gu[j] + c.Wr[j] * (us[j] - yr[(size_t)k * NY + NX + j]);
+            const T tol = T(1e-9) * (T(1) + fabs(c.lbu[j]) + fabs(c.ubu[j]));
+            T pg = g;
+            if (us[j] <= c.lbu[j] + tol) pg = fmin(g, T(0));           // at the lower bound only a negative gradient is a violation
+            else if (us[j] >= c.ubu[j] - tol) pg = fmax(g, T(0));
+            rs = fmax(rs, fabs(pg));
+            rb = fmax(rb, fmax(c.lbu[j] - us[j], us[j] - c.ubu[j]));
+        }
+    }
+    res[(size_t)b * 3] = rs; res[(size_t)b * 3 + 1] = rd; res[(size_t)b * 3 + 2] = fmax(rb, T(0));
+}
+
 }  // namespace nmpc

@@ -82,10 +82,10 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
 // per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
 template <bool SHARED, bool TRAJ, int OCC>
 __global__ __launch_bounds__(64, OCC) void k_team_as(Consts<double> c, Work<double> w, Inputs<double> in, Outputs<double> out,
-                                                     TeamWork<double> tw, WorkList wl, int B, int tpw)
+                                                     TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    team_as<SHARED, TRAJ>(c, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw));
+    team_as<SHARED, TRAJ, OCC == 1>(c, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
 }
 
 // default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
@@ -125,6 +125,7 @@ struct nmpc_solver {
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
     int *d_wl = nullptr;             // work list of the split FP64 path: count | done | list [Bp]
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
+    int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
     void *s_x0 = nullptr, *s_yref = nullptr, *s_yref_e = nullptr, *s_xi = nullptr, *s_ui = nullptr;
@@ -137,7 +138,8 @@ struct nmpc_solver {
     size_t pack_in_bytes = 0, pack_out_bytes = 0;
     hipStream_t pack_stream = nullptr;
     uint64_t ws_bytes = 0;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start | after prepare | after the (first) solve kernel | after the work-list launch
+    bool timed_split = false, last_split = false;
     int last_B = 0;
     bool timed = false, timed_fused = false, solved = false;
     bool timing = true;   // nmpc_set_timing: HIP events around the kernels of every solve
@@ -301,6 +303,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -422,26 +425,33 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
             if (split) {
                 WorkList wl;
                 wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
-                const size_t lds_as = (size_t)4 * (c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE) * sizeof(double);
                 const int nlist = std::min((B + 3) / 4, 128);
                 const bool traj = x_out != nullptr || u_out != nullptr;
                 int occ_as = s->team_occ;
                 // two waves per SIMD need >= 2048 waves; the per-stage variant spills inside its sweeps at 256 registers
                 // (measured slower than one wave per SIMD at every batch size), so only the shared variant takes it
                 if (occ_as == 0) occ_as = (c.shared && (B + tpw - 1) / tpw >= 2048) ? 2 : 1;
-#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw); \
-                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw); } while (0)
-                if (c.shared) {
-                    if (traj) NMPC_LAUNCH_AS(true, true); else NMPC_LAUNCH_AS(true, false);
-                    hipLaunchKernelGGL(k_team_ipm_list<true>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-                } else {
-                    if (traj) NMPC_LAUNCH_AS(false, true); else NMPC_LAUNCH_AS(false, false);
-                    hipLaunchKernelGGL(k_team_ipm_list<false>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-                }
+                // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD,
+                // 20 KB at two) holds the factors of the first stages; the team stride stays 192 B past a multiple of
+                // the 256-B bank row (24 doubles mod 32)
+                const int base_as = c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+                const int per_team = (occ_as == 2 ? 20480 : 40960) / 4 / (int)sizeof(double);
+                int lstg = occ_as == 2 ? 0 : std::max(0, std::min(s->cfg.N, (per_team - base_as - 31) / AS_LM_ROWS));   // the two-waves build carries no cache
+                if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
+                int lds_stride = base_as + lstg * AS_LM_ROWS;
+                lds_stride += (24 - lds_stride % 32 + 32) % 32;
+                const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
+#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw, lds_stride, lstg); \
+                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw, lds_stride, lstg); } while (0)
+                if (c.shared) { if (traj) NMPC_LAUNCH_AS(true, true); else NMPC_LAUNCH_AS(true, false); }
+                else { if (traj) NMPC_LAUNCH_AS(false, true); else NMPC_LAUNCH_AS(false, false); }
+                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
+                if (c.shared) hipLaunchKernelGGL(k_team_ipm_list<true>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+                else hipLaunchKernelGGL(k_team_ipm_list<false>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
 #undef NMPC_LAUNCH_AS
                 HIP_TRY(s, hipGetLastError());
-                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true;
+                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
+                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
                 return 0;
             }
         }
@@ -467,6 +477,8 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     s->solved = true;
     s->timed = s->timing;
     s->timed_fused = fused != 0;
+    s->timed_split = false;
+    s->last_split = false;
     return 0;
 }
 
@@ -778,6 +790,53 @@ int nmpc_hold_command_device(nmpc_solver *s, int B, const void *u0, const int32_
     return 0;
 }
 
+int nmpc_adjoint_sensitivities_device(nmpc_solver *s, int B, const void *x, const void *u, const void *lam, void *out,
+                                      int continuous, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !x || !u || !lam || !out) return s->fail(NMPC_EARG, "adjoint_sensitivities: bad arguments");
+    if (!continuous && s->cfg.sim_num_steps > ADJ_MAX_STEPS)
+        return s->fail(NMPC_EARG, "adjoint_sensitivities: sim_num_steps > %d is not built", ADJ_MAX_STEPS);
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const dim3 grid((B + 63) / 64), block(64);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Consts<double> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_adjoint_sens<double>, grid, block, 0, st, c, B, (const double *)x, (const double *)u, (const double *)lam, (double *)out, continuous);
+    } else {
+        Consts<float> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_adjoint_sens<float>, grid, block, 0, st, c, B, (const float *)x, (const float *)u, (const float *)lam, (float *)out, continuous);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void *u_traj, const void *yref, const void *yref_e,
+                           int yref_bcast, void *res, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !x_traj || !u_traj || !yref || !yref_e || !res) return s->fail(NMPC_EARG, "kkt_report: bad arguments");
+    if (s->cfg.sim_num_steps > ADJ_MAX_STEPS) return s->fail(NMPC_EARG, "kkt_report: sim_num_steps > %d is not built", ADJ_MAX_STEPS);
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const dim3 grid((B + 63) / 64), block(64);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Consts<double> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_kkt_report<double>, grid, block, 0, st, c, B, (const double *)x_traj, (const double *)u_traj, (const double *)yref,
+                           (const double *)yref_e, yref_bcast, (double *)res);
+    } else {
+        Consts<float> c;
+        fill_consts(s->cfg, c);
+        hipLaunchKernelGGL(k_kkt_report<float>, grid, block, 0, st, c, B, (const float *)x_traj, (const float *)u_traj, (const float *)yref,
+                           (const float *)yref_e, yref_bcast, (float *)res);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
 int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next, int normalize_q,
                            void *hip_stream)
 {
@@ -842,6 +901,11 @@ int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out)
         }
         out->ms_prepare = a;
         out->ms_solve = b;
+        if (s->timed_split) {
+            float t = 0;
+            HIP_TRY(s, hipEventElapsedTime(&t, s->ev[2], s->ev[3]));
+            out->ms_tail = t;
+        }
     }
     const int B = s->last_B;
     std::vector<int32_t> it(B), st(B);
@@ -866,6 +930,10 @@ int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out)
         out->n_polished += (np[i] > 0);
     }
     out->polish_mean = psum / B;
+    // handed to the general kernel = not settled by the first active-set attempt: such an instance goes on with at least one
+    // interior-point iteration (the active-set kernel itself makes none)
+    if (s->last_split)
+        for (int i = 0; i < B; i++) out->n_tail += it[i] > 0;
     return 0;
 }
 

@@ -226,6 +226,72 @@ NMPC_HD void erk_sens(const Consts<T> &c, const T *x, const T *u, T *xn, T S[11]
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Adjoint sensitivities (the CasADi-generated `expl_vde_adj` of the reference's model,
+// controller.py:267-355).  model_adj is the continuous adjoint right-hand side
+//     ( f_x(x,u)' lam , f_u(x,u)' lam )
+// from the hand-derived sparse Jacobian blocks of model_jac (p rows: d pdot / d v = I; v rows: Fvq and the
+// thrust direction r3m; q rows: Fqq, Fqw; omega rows: Fww and the rotor geometry fuw); erk_adjoint is its
+// discrete counterpart: the reverse sweep through the controller's integrator (explicit midpoint x steps),
+// i.e. [A B]' lam of one shooting interval WITHOUT forming A and B - what a reverse-mode (adjoint) RTI would
+// use, and what the stationarity report below is built on.  In Gauss-Newton mode acados does not call
+// expl_vde_adj on the solve path (it multiplies with the stored [B A]'), so neither do the solve kernels.
+template <class T>
+NMPC_HD void model_adj(const Consts<T> &c, const Jac<T> &J, const T *lam, T *ax /*13*/, T *au /*4*/)
+{
+    NMPC_UNROLL for (int i = 0; i < 3; i++) { ax[i] = 0; ax[3 + i] = lam[i]; }
+    NMPC_UNROLL for (int l = 0; l < 4; l++) {
+        T a = 0;
+        NMPC_UNROLL for (int i = 0; i < 3; i++) a += J.Fvq[i][l] * lam[3 + i];
+        NMPC_UNROLL for (int i = 0; i < 4; i++) a += J.Fqq[i][l] * lam[6 + i];
+        ax[6 + l] = a;
+    }
+    NMPC_UNROLL for (int l = 0; l < 3; l++) {
+        T a = 0;
+        NMPC_UNROLL for (int i = 0; i < 4; i++) a += J.Fqw[i][l] * lam[6 + i];
+        NMPC_UNROLL for (int i = 0; i < 3; i++) a += J.Fww[i][l] * lam[10 + i];
+        ax[10 + l] = a;
+    }
+    const T tv = J.r3m[0] * lam[3] + J.r3m[1] * lam[4] + J.r3m[2] * lam[5];
+    NMPC_UNROLL for (int j = 0; j < NU; j++)
+        au[j] = tv + c.fuw[0][j] * lam[10] + c.fuw[1][j] * lam[11] + c.fuw[2][j] * lam[12];
+}
+
+// x+ = phi(x,u) (explicit midpoint x c.steps), then lam <- A' lam, gu <- B' lam by the reverse sweep.  MAXS = steps kept.
+template <class T, int MAXS>
+NMPC_HD void erk_adjoint(const Consts<T> &c, const T *x, const T *u, T *lam /*in: adjoint of x+, out: A' lam*/, T *gu /*B' lam*/,
+                         T *xnext /*nullable*/)
+{
+    T xs[MAXS][NX], xm[MAXS][NX], xc[NX];
+    NMPC_UNROLL for (int i = 0; i < NX; i++) xc[i] = x[i];
+    const int ns = c.steps < MAXS ? c.steps : MAXS;
+    for (int st = 0; st < ns; st++) {
+        T f1[NX], f2[NX];
+        model_f(c, xc, u, f1);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) { xs[st][i] = xc[i]; xm[st][i] = xc[i] + T(0.5) * c.h * f1[i]; }
+        model_f(c, xm[st], u, f2);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xc[i] += c.h * f2[i];
+    }
+    if (xnext) { NMPC_UNROLL for (int i = 0; i < NX; i++) xnext[i] = xc[i]; }
+    NMPC_UNROLL for (int j = 0; j < NU; j++) gu[j] = 0;
+    for (int st = ns - 1; st >= 0; st--) {
+        // x+ = x + h f(xm,u), xm = x + h/2 f(x,u):  lam_m = h f_x(xm)' lam+,  lam = lam+ + lam_m + h/2 f_x(x)' lam_m
+        Jac<T> J;
+        T lm[NX], ax[NX], au[NU];
+        model_jac(c, xm[st], u, J);
+        model_adj(c, J, lam, ax, au);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) lm[i] = c.h * ax[i];
+        NMPC_UNROLL for (int j = 0; j < NU; j++) gu[j] += c.h * au[j];
+        model_jac(c, xs[st], u, J);
+        model_adj(c, J, lm, ax, au);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) lam[i] += lm[i] + T(0.5) * c.h * ax[i];
+        NMPC_UNROLL for (int j = 0; j < NU; j++) gu[j] += T(0.5) * c.h * au[j];
+    }
+}
+
+constexpr int ADJ_MAX_STEPS = 4;
+
+
 // ---------------------------------------------------------------------------------------
 // Riccati stage helpers.  Ad[79] (column-packed), Bm[13][4].
 template <class T>

@@ -37,6 +37,7 @@ namespace nmpc {
 constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
 constexpr int AS_EV = 32;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2
 constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
+constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 // LDS carve per team, in doubles
 constexpr int A_AD = 0;              // [16][8]  rows of the dense A columns (natural layout)
 constexpr int A_B = A_AD + 128;      // [16][4]
@@ -74,17 +75,22 @@ struct WorkList {
     int *list;      // [Bp] instance indices
 };
 
-template <bool SHARED, bool TRAJ>
+template <bool SHARED, bool TRAJ, bool LDSC>
 __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<double> &in,
                                         const Outputs<double> &out, const TeamWork<double> &tw, const WorkList &wl,
-                                        int B, int tpw, double *smem)
+                                        int B, int tpw, double *smem, int lds_stride, int lstg)
 {
+    // lds_stride: doubles of LDS per team (carve below + the stage cache); lstg: the factors of stages 0 .. lstg-1 -
+    // written last by the backward sweep and read first by the forward sweep - stay in LDS and never reach HBM
     // SHARED: cold start with one linearisation for all stages (x_k = x0, u_k = 0 folded at compile time)
     // TRAJ:   the caller wants x_out / u_out: the forward sweep also leaves xhat_k and every candidate input
+    // LDSC:   the build carries the LDS stage cache (one wave per SIMD: 40 KB of LDS per wave); without it
+    //         lstg must be 0 and the code is the plain HBM-scratch form (two waves per SIMD: 20 KB per wave)
     using T = double;
     using NoPins = std::integral_constant<bool, false>;
     using WithPins = std::integral_constant<bool, true>;
-    constexpr int LDS_T = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    constexpr int A_LM = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;      // stage cache: [lstg][AS_LM_ROWS]
+    const int LDS_T = lds_stride;
     NMPC_PROF_BEGIN
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
     const int ta = r >> 2, tc = r & 3, j = tc;
@@ -99,7 +105,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     const int N = c.N;
     T *S = smem + team * LDS_T;
     T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sD = S + A_D, *sh = S + A_H, *sXh = S + A_XH;
-    T *sRed = S + A_RED, *sEv = S + A_EV;
+    T *sRed = S + A_RED, *sEv = S + A_EV, *sLM = S + A_LM;
     const bool warm = !SHARED && in.x_init != nullptr && in.u_init != nullptr;
     const T *x0p = in.x0 + (size_t)inst * NX;
     const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
@@ -318,8 +324,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             T n_yx = yr[(size_t)ks * NY + rr], n_yu = yr[(size_t)ks * NY + NX + cu];
             T n_xl = xlin(ks), n_ul = ulin(ks, cu);
             T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
-            auto stage = [&](int k, auto last_tag) {
+            auto stage = [&](int k, auto last_tag, auto lds_tag) {
                 constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
+                constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
                 if (!SHARED) { put_stage(); if (!LAST) fetch_stage(k - 1); load_tiles(); }
                 T *lmk = tLM + k * TLM_ROWS;
                 const T ul = n_ul, pc = n_pc;
@@ -458,9 +465,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 T M[4];
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     M[jt] = mfma44(Y, X[jt], T(0));
-                    lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];              // where the forward sweep reads it transposed
+                    // stored where the forward sweep reads it transposed
+                    if (LDSST) sLM[k * AS_LM_ROWS + jt * 16 + tc * 4 + ta] = M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
                 }
-                lmk[TLM_Z + r] = mfma44(Y, Idt, T(0));                        // Y' = L^-1 as a tile
+                const T Zt = mfma44(Y, Idt, T(0));                            // Y' = L^-1 as a tile
+                if (LDSST) sLM[k * AS_LM_ROWS + 64 + r] = Zt; else lmk[TLM_Z + r] = Zt;
                 if (!LAST) {
                     T Mn[4];
                     NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M[t];
@@ -476,8 +485,18 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 }
                 NMPC_WSYNC();
             };
-            for (int k = ks; k > 0; k--) stage(k, std::integral_constant<bool, false>{});
-            stage(0, std::integral_constant<bool, true>{});
+            using Fl = std::integral_constant<bool, false>;
+            using Tr = std::integral_constant<bool, true>;
+            int k = ks;
+            if constexpr (LDSC) {
+                const int kg = lstg > 1 ? lstg : 1;
+                for (; k >= kg; k--) stage(k, Fl{}, Fl{});        // factors to HBM
+                for (; k > 0; k--) stage(k, Fl{}, Tr{});          // factors stay in LDS
+                if (lstg > 0) stage(0, Tr{}, Tr{}); else stage(0, Tr{}, Fl{});
+            } else {
+                for (; k > 0; k--) stage(k, Fl{}, Fl{});
+                stage(0, Tr{}, Fl{});
+            }
         };
         if (pass == 0) sweepA(NoPins{}); else sweepA(WithPins{});
         NMPC_STAMP(0)
@@ -515,6 +534,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
             const int cslot = tc == 0 ? 12 + ta : 0, pslot = tc == 0 ? 16 + ta : 0;
             struct Ops { T mt[4], z, ul, pc; };
+            // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon)
             auto fetch_ops = [&](int kq, Ops &o) {
                 const int k = kq < N ? kq : N - 1;
                 const T *lmn = tLM + k * TLM_ROWS;
@@ -522,6 +542,12 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
                 o.ul = ulin(k, ta);
                 o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
+            };
+            // ... and from the LDS stage cache (scalars still come from global memory, one stage ahead)
+            auto fetch_ops_lds = [&](int k, Ops &o) {
+                const T *lmn = sLM + k * AS_LM_ROWS;
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[jt * 16 + r];
+                o.z = lmn[64 + r];
             };
             auto stageB = [&](int k, const Ops &o) {
                 if (!SHARED) { put_stage(); if (k + 1 < N) fetch_stage(k + 1); load_tiles_T(); }
@@ -576,8 +602,24 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
             };
             Ops oa[2], ob[2];
-            fetch_ops(0, oa[0]); fetch_ops(1, oa[1]);
-            for (int k0 = 0; k0 < N; k0 += 4) {
+            const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // stages [0, kl) come from LDS, [kl, N) from HBM
+            fetch_ops(kl, oa[0]); fetch_ops(kl + 1, oa[1]);     // the first HBM stages are in flight during the LDS phase
+            if constexpr (LDSC) {
+                if (kl > 0) {
+                    Ops ol;
+                    T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
+                    fetch_ops_lds(0, ol);
+                    for (int k = 0; k < kl; k++) {
+                        ol.ul = n_ul; ol.pc = n_pc;
+                        const int kn = k + 1 < N ? k + 1 : k;
+                        n_ul = ulin(kn, ta);
+                        if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
+                        stageB(k, ol);
+                        if (k + 1 < kl) fetch_ops_lds(k + 1, ol);
+                    }
+                }
+            }
+            for (int k0 = kl; k0 < N; k0 += 4) {
                 fetch_ops(k0 + 2, ob[0]); fetch_ops(k0 + 3, ob[1]);
                 stageB(k0, oa[0]);
                 if (k0 + 1 < N) stageB(k0 + 1, oa[1]);

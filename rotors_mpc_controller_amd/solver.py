@@ -149,6 +149,18 @@ class NmpcOcpSolver:
         self._check(self._lib.nmpc_plant_step_device(self._h, int(B), x_ptr, u_ptr, x_next_ptr, int(normalize_q),
                                                      stream or None))
 
+    def adjoint_sensitivities_device(self, B: int, x_ptr: int, u_ptr: int, lam_ptr: int, out_ptr: int,
+                                     continuous: bool = False, stream: int = 0) -> None:
+        """(A' lam | B' lam) of one shooting interval per instance (continuous: (f_x' lam | f_u' lam), = expl_vde_adj)."""
+        self._check(self._lib.nmpc_adjoint_sensitivities_device(self._h, int(B), x_ptr, u_ptr, lam_ptr, out_ptr,
+                                                                int(bool(continuous)), stream or None))
+
+    def kkt_report_device(self, B: int, x_traj_ptr: int, u_traj_ptr: int, yref_ptr: int, yref_e_ptr: int, yref_bcast: bool,
+                          res_ptr: int, stream: int = 0) -> None:
+        """res [B,3] = (projected input-gradient, dynamics defect, bound violation) of trajectories, by an adjoint sweep."""
+        self._check(self._lib.nmpc_kkt_report_device(self._h, int(B), x_traj_ptr, u_traj_ptr, yref_ptr, yref_e_ptr,
+                                                     int(bool(yref_bcast)), res_ptr, stream or None))
+
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 
@@ -166,7 +178,7 @@ class NmpcOcpSolver:
         return dict(batch=st.batch, iter_min=st.iter_min, iter_max=st.iter_max, iter_mean=st.iter_mean,
                     n_status=list(st.n_status), ms_prepare=st.ms_prepare, ms_solve=st.ms_solve,
                     workspace_bytes=int(st.workspace_bytes), polish_mean=st.polish_mean, polish_max=st.polish_max,
-                    n_polished=st.n_polished)
+                    n_polished=st.n_polished, n_tail=st.n_tail, ms_tail=st.ms_tail)
 
 
 # name a maintainer would import in place of acados_template's class

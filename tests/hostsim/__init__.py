@@ -31,6 +31,8 @@ def lib():
         _lib.hostsim_solve_batch.argtypes = [C.POINTER(NmpcConfig), C.c_int, dp, dp, dp, C.c_int, dp, dp,
                                              dp, ip, dp, dp, ip]
         _lib.hostsim_solve_batch.restype = C.c_int
+        _lib.hostsim_adjoint.argtypes = [C.POINTER(NmpcConfig), C.c_int, dp, dp, dp, dp, C.c_int]
+        _lib.hostsim_adjoint.restype = C.c_int
     return _lib
 
 
@@ -51,3 +53,12 @@ def solve_batch(cfg: NmpcConfig, x0, yref, yref_e, x_init=None, u_init=None):
     lib().hostsim_solve_batch(C.byref(cfg), B, _p(x0), _p(yref), _p(yref_e), bcast, _p(xi), _p(ui),
                               _p(u0), _p(st, C.c_int32), _p(xo), _p(uo), _p(it, C.c_int32))
     return dict(u0=u0, status=st, iters=it, x=xo, u=uo)
+
+
+def adjoint(cfg: NmpcConfig, x, u, lam, continuous: bool = False):
+    """(A' lam | B' lam) per instance from the host build of model_adj / erk_adjoint (nmpc_lane.hpp)."""
+    x = np.ascontiguousarray(x, dtype=np.float64); u = np.ascontiguousarray(u, dtype=np.float64)
+    lam = np.ascontiguousarray(lam, dtype=np.float64)
+    out = np.zeros((x.shape[0], 17))
+    lib().hostsim_adjoint(C.byref(cfg), x.shape[0], _p(x), _p(u), _p(lam), _p(out), int(continuous))
+    return out

@@ -61,3 +61,27 @@ extern "C" int hostsim_solve_batch(const nmpc_config *g, int B, const double *x0
     else run<float>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);
     return 0;
 }
+
+// adjoint sensitivities (nmpc_lane.hpp model_adj / erk_adjoint) of one interval per instance, FP64:
+// out [B][17] = (A' lam | B' lam), or (f_x' lam | f_u' lam) when cont != 0
+extern "C" int hostsim_adjoint(const nmpc_config *g, int B, const double *x, const double *u, const double *lam, double *out, int cont)
+{
+    Consts<double> c;
+    fill_consts(*g, c);
+    for (int b = 0; b < B; b++) {
+        double l[NX], gu[NU];
+        for (int i = 0; i < NX; i++) l[i] = lam[(size_t)b * NX + i];
+        if (cont) {
+            Jac<double> J;
+            double ax[NX];
+            model_jac(c, x + (size_t)b * NX, u + (size_t)b * NU, J);
+            model_adj(c, J, l, ax, gu);
+            for (int i = 0; i < NX; i++) l[i] = ax[i];
+        } else {
+            erk_adjoint<double, ADJ_MAX_STEPS>(c, x + (size_t)b * NX, u + (size_t)b * NU, l, gu, nullptr);
+        }
+        for (int i = 0; i < NX; i++) out[(size_t)b * (NX + NU) + i] = l[i];
+        for (int i = 0; i < NU; i++) out[(size_t)b * (NX + NU) + NX + i] = gu[i];
+    }
+    return 0;
+}
