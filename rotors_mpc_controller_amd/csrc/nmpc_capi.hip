@@ -81,11 +81,13 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
 // OCC = waves per SIMD the register allocation allows: 2 (256 registers) pays once the batch supplies two waves
 // per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
 template <bool SHARED, bool TRAJ, int OCC>
-__global__ __launch_bounds__(64, OCC) void k_team_as(Consts<double> c, Work<double> w, Inputs<double> in, Outputs<double> out,
+__global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<double> in, Outputs<double> out,
                                                      TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    team_as<SHARED, TRAJ, OCC == 1>(c, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
+    // the constant block is read from device memory (uploaded at create): scalar loads on demand for uniform entries,
+    // one vector load for a per-lane entry
+    team_as<SHARED, TRAJ, OCC == 1>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
 }
 
 // default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
@@ -124,6 +126,7 @@ struct nmpc_solver {
     void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *tP = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
     int *d_wl = nullptr;             // work list of the split FP64 path: count | done | list [Bp]
+    void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
@@ -244,6 +247,12 @@ static int alloc_ws(nmpc_solver *s)
         s->ws_bytes += x.n;
     }
     HIP_TRY(s, hipMemset(s->d_wl, 0, (Bp + 2) * sizeof(int)));
+    {
+        Consts<double> cd;
+        fill_consts(s->cfg, cd);
+        HIP_TRY(s, hipMalloc(&s->d_consts, sizeof(cd)));
+        HIP_TRY(s, hipMemcpy(s->d_consts, &cd, sizeof(cd), hipMemcpyHostToDevice));
+    }
     if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
         CondWork<double> cw;
         const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
@@ -333,7 +342,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->d_consts, s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -441,8 +450,8 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                 int lds_stride = base_as + lstg * AS_LM_ROWS;
                 lds_stride += (24 - lds_stride % 32 + 32) % 32;
                 const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
-#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw, lds_stride, lstg); \
-                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, c, w, in, out, tw, wl, B, tpw, lds_stride, lstg); } while (0)
+#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, (const Consts<double> *)s->d_consts, w, in, out, tw, wl, B, tpw, lds_stride, lstg); \
+                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, (const Consts<double> *)s->d_consts, w, in, out, tw, wl, B, tpw, lds_stride, lstg); } while (0)
                 if (c.shared) { if (traj) NMPC_LAUNCH_AS(true, true); else NMPC_LAUNCH_AS(true, false); }
                 else { if (traj) NMPC_LAUNCH_AS(false, true); else NMPC_LAUNCH_AS(false, false); }
                 if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));

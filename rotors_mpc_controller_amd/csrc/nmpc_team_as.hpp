@@ -128,12 +128,18 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     T dt_v = c.dt, kkt_v = c.kkt_tol;
     asm volatile("" : "+v"(dt_v), "+v"(kkt_v));
     const T x0r = x0p[rr];
-    const T Wq_r = pick13(c.Wq, rr), WqN_r = pick13(c.WqN, rr);
-    const T Wr_j = sel4(c.Wr, j), Wr_a = sel4(c.Wr, ta);
-    const T lbj = sel4(c.lbu, j), ubj = sel4(c.ubu, j), Rdj = sel4(c.Rd, j);
-    const T lb_a = sel4(c.lbu, ta), ub_a = sel4(c.ubu, ta), Rd_a = sel4(c.Rd, ta);
+    // (c lives in device memory: an entry picked by a lane-dependent index is ONE vector load, where the by-value
+    // constant block cost a 13-way select chain per entry and 190 scalar registers - 584 of the 1413 instructions
+    // in front of the first MFMA were scalar-register spill traffic)
+    const T Wq_r = c.Wq[rr], WqN_r = c.WqN[rr];
+    const T Wr_j = c.Wr[j], Wr_a = c.Wr[ta];
+    const T lbj = c.lbu[j], ubj = c.ubu[j], Rdj = c.Rd[j];
+    const T lb_a = c.lbu[ta], ub_a = c.ubu[ta], Rd_a = c.Rd[ta];
     T Qdg[4];                              // diagonal of the stage Hessian in tile layout
-    NMPC_UNROLL for (int t = 0; t < 4; t++) Qdg[t] = (ta == tc && natR[t] >= 0) ? pick13(c.Qd, natR[t]) : T(0);
+    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+        const T qd = c.Qd[natR[t] >= 0 ? natR[t] : 0];
+        Qdg[t] = (ta == tc && natR[t] >= 0) ? qd : T(0);
+    }
     const int polish_passes = c.polish_passes;
     const T Idt = (ta == tc) ? T(1) : T(0);
     const T HuuD = (ta == tc) ? Rd_a : T(0);          // diagonal of Huu without pins
@@ -304,7 +310,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_WSYNC();
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                        T v = (it == jt && ta == tc && natR[it] >= 0) ? pick13(c.QdN, natR[it]) : T(0);
+                        T v = (it == jt && ta == tc && natR[it] >= 0) ? c.QdN[natR[it] >= 0 ? natR[it] : 0] : T(0);
                         const T qa = sh[natR[it] >= 0 ? natR[it] : 0], qb = sh[natC[jt] >= 0 ? natC[jt] : 0];
                         if (jt == 3 && tc == 3 && natR[it] >= 0) v = qa;
                         if (it == 3 && ta == 3 && natC[jt] >= 0) v = qb;
