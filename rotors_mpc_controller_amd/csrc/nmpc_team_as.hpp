@@ -186,40 +186,57 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             }
             NMPC_WSYNC();
             NMPC_STAMP(3)
-            // ---- phase B: forward sensitivities of every stage of the chunk, tile form
-            for (int e = 0; e < CH; e++) {
-                const int k = k0 + e;
-                if (k >= Ns) break;
-                const T *ev = sEv + e * AS_EV;
-                const T t2 = ev[28];
-                T Sx[4][3];
-                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                    NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[rt][ct] = 0;
+            // ---- phase B: forward sensitivities of the stages of the chunk, tile form, TWO stages at a time: their MFMA
+            // chains are independent, so one stage's variational-equation products run in the latency of the other's
+            constexpr int PB = SHARED ? 1 : 2;
+            for (int e0 = 0; e0 < CH; e0 += PB) {
+                if (k0 + e0 >= Ns) break;
+                const T *ev[PB];
+                T t2[PB], Sx[PB][4][3];
+                NMPC_UNROLL for (int q = 0; q < PB; q++) {
+                    const int e = (e0 + q < CH && k0 + e0 + q < Ns) ? e0 + q : e0;      // an odd tail repeats the last stage
+                    ev[q] = sEv + e * AS_EV;
+                    t2[q] = ev[q][28];
+                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                        NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[q][rt][ct] = 0;
+                    }
+                    Sx[q][2][0] = (ta == tc) ? T(1) : T(0);                  // d q / d q = I
+                    Sx[q][3][1] = (ta == tc && ta < 3) ? T(1) : T(0);        // d w / d w = I
                 }
-                Sx[2][0] = (ta == tc) ? T(1) : T(0);                  // d q / d q = I
-                Sx[3][1] = (ta == tc && ta < 3) ? T(1) : T(0);        // d w / d w = I
                 for (int st = 0; st < nsteps; st++) {
-                    T K[4][3], Sm[4][3];
-                    T a1, a2, a3, a4, a5;
-                    jac_tiles_ev(inv_mass, jk, ev + st * 14, t2, ta, a1, a2, a3, a4, a5);
-                    vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx, K);
-                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                        NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[rt][ct] = Sx[rt][ct] + hh * K[rt][ct];
+                    T K[PB][4][3], Sm[PB][4][3];
+                    NMPC_UNROLL for (int q = 0; q < PB; q++) {
+                        T a1, a2, a3, a4, a5;
+                        jac_tiles_ev(inv_mass, jk, ev[q] + st * 14, t2[q], ta, a1, a2, a3, a4, a5);
+                        vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx[q], K[q]);
                     }
-                    jac_tiles_ev(inv_mass, jk, ev + st * 14 + 7, t2, ta, a1, a2, a3, a4, a5);
-                    vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm, K);
-                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                        NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[rt][ct] += hstep * K[rt][ct];
+                    NMPC_UNROLL for (int q = 0; q < PB; q++) {
+                        NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[q][rt][ct] = Sx[q][rt][ct] + hh * K[q][rt][ct];
+                        }
+                    }
+                    NMPC_UNROLL for (int q = 0; q < PB; q++) {
+                        T a1, a2, a3, a4, a5;
+                        jac_tiles_ev(inv_mass, jk, ev[q] + st * 14 + 7, t2[q], ta, a1, a2, a3, a4, a5);
+                        vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm[q], K[q]);
+                    }
+                    NMPC_UNROLL for (int q = 0; q < PB; q++) {
+                        NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[q][rt][ct] += hstep * K[q][rt][ct];
+                        }
                     }
                 }
-                {                             // natural layout: Ad rows [13][8] | B rows [13][4] (b came from phase A)
-                    T *a = SHARED ? S : tAB + (size_t)k * TAB_ROWS;
-                    const int oA = SHARED ? A_AD : 0, oB = SHARED ? A_B : 104;
-                    NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                        if (natR[rt] >= 0) {
-                            a[oA + natR[rt] * 8 + tc] = Sx[rt][0];
-                            a[oA + natR[rt] * 8 + 4 + tc] = tc < 3 ? Sx[rt][1] : T(0);
-                            a[oB + natR[rt] * NU + tc] = Sx[rt][2];
+                NMPC_UNROLL for (int q = 0; q < PB; q++) {      // natural layout: Ad rows [13][8] | B rows [13][4] (b came from phase A)
+                    const int k = k0 + e0 + q;
+                    if (q == 0 || (e0 + q < CH && k < Ns)) {
+                        T *a = SHARED ? S : tAB + (size_t)k * TAB_ROWS;
+                        const int oA = SHARED ? A_AD : 0, oB = SHARED ? A_B : 104;
+                        NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                            if (natR[rt] >= 0) {
+                                a[oA + natR[rt] * 8 + tc] = Sx[q][rt][0];
+                                a[oA + natR[rt] * 8 + 4 + tc] = tc < 3 ? Sx[q][rt][1] : T(0);
+                                a[oB + natR[rt] * NU + tc] = Sx[q][rt][2];
+                            }
                         }
                     }
                 }

@@ -64,3 +64,55 @@ def test_world_size_2_gather_equals_single_process():
     ref = H.solve_batch(cfg, sample_x0(total, 11, **AGGRESSIVE), yref, ye)
     np.testing.assert_array_equal(st, ref["status"])
     np.testing.assert_array_equal(u0, ref["u0"])
+
+
+def _worker_cfg4(rank, world, port, q):
+    """BASELINE config 4 in miniature on CPU: equal shards of 4096 (seed 100 + rank), no data-path collective, one
+    all-gather of u0 / status per tick (all_gather_commands) and the grouped form bench.py uses (G ticks per collective,
+    asynchronous handle, [world][G][B][4] layout)."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from oracle import oracle as O
+    from rotors_mpc_controller_amd.distributed import all_gather_commands, rank_seed
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER
+    B = 4096
+    c = O.default_config(qp_gamma=0.0, qp_polish=1)
+    yref, ye = O.hover_yref(c)
+    out = O.solve_batch(c, sample_x0(B, rank_seed(rank), **NEAR_HOVER), yref, ye, nthreads=3)
+    u0, st = torch.from_numpy(out["u0"]), torch.from_numpy(out["status"].astype(np.int32))
+    g_u, g_s = all_gather_commands(u0, st)
+    # grouped exchange: G consecutive ticks share one asynchronous all-gather (tick t carries u0 + t here)
+    G = 3
+    grp = torch.stack([u0 + float(t) for t in range(G)])                       # [G][B][4]
+    gathered = torch.zeros(world, G, B, 4, dtype=torch.float64)
+    h = dist.all_gather_into_tensor(gathered.view(world * G * B, 4), grp.view(G * B, 4), async_op=True)
+    h.wait()
+    if rank == 0:
+        q.put((g_u.numpy(), g_s.numpy(), gathered.numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_equal_shards_of_4096_all_gather_commands_and_grouped_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_cfg4, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    g_u, g_s, grouped = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from oracle import oracle as O
+    from rotors_mpc_controller_amd.distributed import rank_seed
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER
+    c = O.default_config(qp_gamma=0.0, qp_polish=1)
+    yref, ye = O.hover_yref(c)
+    assert g_u.shape == (2 * 4096, 4) and g_s.shape == (2 * 4096,)
+    for r in range(2):
+        ref = O.solve_batch(c, sample_x0(4096, rank_seed(r), **NEAR_HOVER), yref, ye, nthreads=6)
+        np.testing.assert_array_equal(g_u[r * 4096:(r + 1) * 4096], ref["u0"])       # rank r's block, original order
+        np.testing.assert_array_equal(g_s[r * 4096:(r + 1) * 4096], ref["status"])
+        for t in range(3):
+            np.testing.assert_array_equal(grouped[r, t], ref["u0"] + float(t))       # [world][G][B][4], as bench.py indexes it
