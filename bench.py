@@ -124,7 +124,8 @@ def secondary_rows(args, B, N, local, dev, tdt, npdt, torch, _lib, NmpcOcpSolver
                 ("plain_ipm", dict(qp_polish=0), x0_near, "qp_polish = 0: Mehrotra interior point only, no active-set passes"),
                 ("aggressive", dict(), x0_aggr, "aggressive x0 set (SURVEY 8d), seed 0: ~28 % of the instances hit a bound")]
     for name, over, x0, what in variants:
-        cfg = _lib.default_config(N=N, max_batch=B, device=local, dtype=_lib.DTYPE_F64 if args.dtype == "f64" else _lib.DTYPE_F32)
+        cfg = _lib.default_config(N=N, max_batch=B, device=local,
+                                  dtype=dict(f64=_lib.DTYPE_F64, f32=_lib.DTYPE_F32, f32io=_lib.DTYPE_F32IO)[args.dtype])
         if args.dtype == "f32":
             cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
         cfg.update(**over)
@@ -191,7 +192,8 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
-    ap.add_argument("--dtype", choices=["f64", "f32"], default="f64")
+    ap.add_argument("--dtype", choices=["f64", "f32", "f32io"], default="f64",
+                    help="f32io: FP32 device buffers, FP64 arithmetic (NMPC_DTYPE_F32IO)")
     ap.add_argument("--dist", choices=["near_hover", "aggressive"], default="near_hover")
     ap.add_argument("--yref", choices=["per_instance", "broadcast"], default="per_instance")
     ap.add_argument("--no-share", action="store_true", help="do not exploit the shared cold-start linearisation")
@@ -240,8 +242,9 @@ def main() -> None:
 
     B, N = args.batch, args.horizon
     tdt, npdt, esz = (torch.float64, np.float64, 8) if args.dtype == "f64" else (torch.float32, np.float32, 4)
+    lib_dtype = dict(f64=_lib.DTYPE_F64, f32=_lib.DTYPE_F32, f32io=_lib.DTYPE_F32IO)[args.dtype]
     cfg = _lib.default_config(N=N, max_batch=B, device=local,
-                              dtype=_lib.DTYPE_F64 if args.dtype == "f64" else _lib.DTYPE_F32,
+                              dtype=lib_dtype,
                               flags=(0 if args.no_share else _lib.FLAG_SHARE_COLD_START)
                               | (_lib.FLAG_TEAM_MAPPING if args.mapping == "team" else 0))
     if args.dtype == "f32":
@@ -356,7 +359,7 @@ def main() -> None:
         alg_b = algorithmic_bytes(N, esz, bcast, args.traj_out)
         n_kkt = n_ipm + st["polish_mean"]
         flops = algorithmic_flops(N, n_kkt)
-        f_peak = FP64_VEC_PEAK_TF if args.dtype == "f64" else FP32_VEC_PEAK_TF
+        f_peak = FP32_VEC_PEAK_TF if args.dtype == "f32" else FP64_VEC_PEAK_TF
         hbm_alg_gbs = alg_b * B / kern_s / 1e9
         alu_tf = flops * B / kern_s / 1e12
         flops_x = executed_flops(N, n_ipm, st["polish_mean"], not args.no_share)
@@ -395,7 +398,7 @@ def main() -> None:
         # FP64 matrix peak of gfx950 equals the vector peak, 78.6 TFLOP/s), so that is the roof quoted for it;
         # every other variant is a vector-ALU kernel and keeps the HBM line of the contract, with the flop
         # figures beside it.  Both sub-objects are always present.
-        mfma_path = args.mapping == "team" and args.dtype == "f64" and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
+        mfma_path = args.mapping == "team" and args.dtype in ("f64", "f32io") and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
         common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else traffic_note),
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + st.get("ms_tail", 0.0), prepare_ms=st["ms_prepare"],
                       launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_ipm_list_ms_isolated=st["ms_tail"],
@@ -409,10 +412,11 @@ def main() -> None:
         line = dict(metric=f"NMPC SQP-RTI solves/sec (N={N}, nx=13, nu=4) at batch={B} per GPU",
                     value=rate, unit="solves/s", n_gpus=world, steps=args.steps, warmup=args.warmup,
                     ms_per_step=ms_step, device_ms_per_step=dev_ms, higher_is_better=True, scaling="weak",
-                    vs_baseline=None, dtype=args.dtype, data="synthetic",
+                    vs_baseline=None, dtype=("f64" if args.dtype == "f32io" else args.dtype), data="synthetic",
                     config=dict(workload=f"batch={B} random x0 around hover ({args.dist}, seed {seed}), N={N}, "
                                          f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
                                 batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
+                                device_buffers=("f32" if args.dtype != "f64" else "f64"),
                                 traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks"),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
                     active_set_passes=dict(mean=st["polish_mean"], max=st["polish_max"], accepted=st["n_polished"]),

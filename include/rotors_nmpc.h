@@ -38,8 +38,11 @@ extern "C" {
 #define NMPC_EARG (-1)
 #define NMPC_EHIP (-2)
 
-#define NMPC_DTYPE_F64 0
-#define NMPC_DTYPE_F32 1
+#define NMPC_DTYPE_F64 0   /* device buffers and arithmetic double */
+#define NMPC_DTYPE_F32 1   /* device buffers and arithmetic float (row-form vector kernels; ~1e-5 N on u0) */
+#define NMPC_DTYPE_F32IO 2 /* device buffers float, arithmetic and workspace DOUBLE: the FP64 tile kernels read and write the
+                              caller's float arrays directly (half the compulsory bytes of F64, u0 exact to float rounding of
+                              the inputs).  Needs the default path: team mapping, qp_polish on, no condensing               */
 
 /* flags */
 #define NMPC_FLAG_SHARE_COLD_START 1u /* cold start: all stages share one (A,B,b); linearise once */
@@ -77,7 +80,7 @@ typedef struct nmpc_config {
     double qp_tau;             /* fraction to the boundary */
     double qp_thr0;            /* initial distance from the bounds, absolute ... */
     double qp_thr0_rel;        /* ... and relative to the box width (the larger applies) */
-    int32_t dtype;             /* NMPC_DTYPE_F64 | NMPC_DTYPE_F32: arithmetic AND device buffers */
+    int32_t dtype;             /* NMPC_DTYPE_F64 | NMPC_DTYPE_F32 | NMPC_DTYPE_F32IO */
     int32_t device;            /* HIP device ordinal */
     int32_t max_batch;         /* workspace is sized for this many instances */
     uint32_t flags;            /* NMPC_FLAG_* */
@@ -150,7 +153,7 @@ int nmpc_solve_batch(nmpc_solver *s, int B, const double *x0, const double *yref
                      const double *u_init, double *u0, int32_t *status, double *x_out,
                      double *u_out);
 
-/* Same, all pointers are DEVICE pointers of element type cfg.dtype (double or float) and
+/* Same, all pointers are DEVICE pointers of the buffer element type of cfg.dtype (double; float for F32 / F32IO) and
  * the work is only enqueued on `hip_stream` (a hipStream_t passed as void*; NULL = default).
  * status is int32 on the device.  This is the entry the benchmark times.                   */
 int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *yref,

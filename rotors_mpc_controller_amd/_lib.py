@@ -12,7 +12,7 @@ from pathlib import Path
 
 NX, NU, NY = 13, 4, 17
 
-DTYPE_F64, DTYPE_F32 = 0, 1
+DTYPE_F64, DTYPE_F32, DTYPE_F32IO = 0, 1, 2     # F32IO: float device buffers, double arithmetic and workspace
 FLAG_SHARE_COLD_START = 1
 FLAG_TEAM_MAPPING = 2
 FLAG_CONDENSED_QP = 4

@@ -80,21 +80,21 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
 // default FP64 path, first launch: preparation + the first active-set attempt (nmpc_team_as.hpp).
 // OCC = waves per SIMD the register allocation allows: 2 (256 registers) pays once the batch supplies two waves
 // per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
-template <bool SHARED, bool TRAJ, int OCC>
-__global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<double> in, Outputs<double> out,
+template <bool SHARED, bool TRAJ, int OCC, class TI>
+__global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
                                                      TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // the constant block is read from device memory (uploaded at create): scalar loads on demand for uniform entries,
     // one vector load for a per-lane entry
-    team_as<SHARED, TRAJ, OCC == 1>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
+    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
 }
 
 // default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
 // the instances the first launch appended to the work list - usually none.  A fixed small grid strides over the
 // list; the last workgroup to finish resets the list for the next solve.
-template <bool SHARED>
-__global__ __launch_bounds__(64, 1) void k_team_ipm_list(Consts<double> c, Work<double> w, Inputs<double> in, Outputs<double> out,
+template <bool SHARED, class TI>
+__global__ __launch_bounds__(64, 1) void k_team_ipm_list(Consts<double> c, Work<double> w, Inputs<TI> in, Outputs<TI> out,
                                                          TeamWork<double> tw, WorkList wl, int B)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
@@ -104,9 +104,9 @@ __global__ __launch_bounds__(64, 1) void k_team_ipm_list(Consts<double> c, Work<
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         const int e = base + team;
         const int inst = e < n ? wl.list[e] : -1;
-        team_prepare(c, w, in, B, 4, smem, inst);
+        team_prepare<double, TI>(c, w, in, B, 4, smem, inst);
         __syncthreads();
-        team_ipm<double, true, SHARED, true>(c, w, out, tw, B, 4, smem, 0ll, SHARED, inst, true);
+        team_ipm<double, true, SHARED, true, TI>(c, w, out, tw, B, 4, smem, 0ll, SHARED, inst, true);
         __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -121,7 +121,8 @@ struct nmpc_solver {
     nmpc_config cfg;
     std::string err;
     int Bp = 0;
-    size_t esz = 8;
+    size_t esz = 8;   // element size of the caller-facing device buffers
+    size_t wsz = 8;   // element size of the workspace = of the arithmetic
     // device workspace (element type = cfg.dtype)
     void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *tP = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
@@ -231,7 +232,7 @@ static int ckpt_stages(const nmpc_config &g)
 
 static int alloc_ws(nmpc_solver *s)
 {
-    const size_t N = (size_t)s->cfg.N, Bp = (size_t)s->Bp, e = s->esz;
+    const size_t N = (size_t)s->cfg.N, Bp = (size_t)s->Bp, e = s->wsz;
     const size_t Bw = Bp + 1;      // per-instance team workspaces carry one spare row: idle teams of a wave work there
     struct { void **p; size_t n; } a[] = {
         {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
@@ -272,7 +273,14 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (cfg->sim_num_stages != 2)
         return bad("nmpc_create: only sim_method_num_stages = 2 (explicit midpoint, controller.py:187) is built");
     if (cfg->sim_num_steps < 1) return bad("nmpc_create: sim_num_steps must be >= 1");
-    if (cfg->dtype != NMPC_DTYPE_F64 && cfg->dtype != NMPC_DTYPE_F32) return bad("nmpc_create: bad dtype");
+    if (cfg->dtype != NMPC_DTYPE_F64 && cfg->dtype != NMPC_DTYPE_F32 && cfg->dtype != NMPC_DTYPE_F32IO) return bad("nmpc_create: bad dtype");
+    if (cfg->dtype == NMPC_DTYPE_F32IO) {
+        const bool ok = (cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP) && cfg->qp_polish &&
+                        cfg->qp_polish_budget > 0 && cfg->qp_polish_passes > 0 && cfg->qp_polish_mu >= cfg->qp_mu0 &&
+                        cfg->sim_num_steps <= AS_MAX_STEPS && !(cfg->qp_mu0 <= cfg->qp_tol_comp);
+        if (!ok) return bad("nmpc_create: NMPC_DTYPE_F32IO runs on the default path only (team mapping, qp_polish = 1 with its first "
+                            "attempt before any interior-point iteration, sim_num_steps <= 2, no condensing)");
+    }
     if (cfg->max_batch < 1) return bad("nmpc_create: max_batch must be >= 1");
     if (!(cfg->mass > 0) || !(cfg->inertia[0] > 0) || !(cfg->inertia[1] > 0) || !(cfg->inertia[2] > 0))
         return bad("nmpc_create: mass and inertia must be positive");
@@ -305,6 +313,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         s->cfg.qp_iter_max = std::min(cfg->qp_iter_max, 30);
     }
     s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
+    s->wsz = cfg->dtype == NMPC_DTYPE_F32 ? 4 : 8;
     if (const char *e = std::getenv("NMPC_TEAM_OCC")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2) s->team_occ = v;
@@ -359,6 +368,80 @@ void nmpc_destroy(nmpc_solver *s)
 const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
 
 }  // extern "C"
+
+// Default FP64 path: the active-set kernel makes the first attempt of every instance; the general kernel runs on the work
+// list of what that attempt could not settle.  TI = element type of the caller's device arrays (double, or float for
+// NMPC_DTYPE_F32IO); arithmetic and workspace are double either way.
+template <class TI>
+static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in, const Outputs<TI> &out,
+                        const TeamWork<double> &tw, int B, int tpw, hipStream_t st)
+{
+    const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);
+    WorkList wl;
+    wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
+    const int nlist = std::min((B + 3) / 4, 128);
+    const bool traj = out.x_out != nullptr || out.u_out != nullptr;
+    const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
+    int occ_as = s->team_occ;
+    // two waves per SIMD need >= 2048 waves; the per-stage variant spills inside its sweeps at 256 registers
+    // (measured slower than one wave per SIMD at every batch size), so only the shared variant takes it
+    if (occ_as == 0) occ_as = ((B + tpw - 1) / tpw >= 2048) ? 2 : 1;
+    if (!c.shared) occ_as = 1;
+    // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD) holds the
+    // factors of the first stages; the team stride stays 192 B past a multiple of the 256-B bank row (24 doubles mod 32).
+    // The two-waves build carries no cache.
+    const int base_as = c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    const int per_team = 40960 / 4 / (int)sizeof(double);
+    int lstg = occ_as == 2 ? 0 : std::max(0, std::min(s->cfg.N, (per_team - base_as - 31) / AS_LM_ROWS));
+    if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
+    int lds_stride = base_as + lstg * AS_LM_ROWS;
+    lds_stride += (24 - lds_stride % 32 + 32) % 32;
+    const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
+    const Consts<double> *cp = (const Consts<double> *)s->d_consts;
+#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), tgrid, tblock, lds_as, st, cp, w, in, out, tw, wl, B, tpw, lds_stride, lstg)
+    if (c.shared) {
+        if (occ_as == 2) { if (traj) NMPC_LAUNCH_AS(true, true, 2); else NMPC_LAUNCH_AS(true, false, 2); }
+        else { if (traj) NMPC_LAUNCH_AS(true, true, 1); else NMPC_LAUNCH_AS(true, false, 1); }
+    } else {
+        if (traj) NMPC_LAUNCH_AS(false, true, 1); else NMPC_LAUNCH_AS(false, false, 1);
+    }
+#undef NMPC_LAUNCH_AS
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
+    if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+    else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+    HIP_TRY(s, hipGetLastError());
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
+    s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
+    return 0;
+}
+
+// NMPC_DTYPE_F32IO: FP64 arithmetic and workspace on the caller's FP32 device arrays (default path only, checked at create)
+static int launch_f32io(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
+                        const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
+{
+    Consts<double> c;
+    fill_consts(s->cfg, c);
+    const bool cold = (x_init == nullptr || u_init == nullptr);
+    c.shared = (cold && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START)) ? 1 : 0;
+    Work<double> w;
+    w.Bp = s->Bp;
+    w.AB = (double *)s->AB; w.bv = (double *)s->bv; w.qr = (double *)s->qr; w.xl = (double *)s->xl; w.ul = (double *)s->ul;
+    w.LM = (double *)s->LM; w.iv = (double *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
+    w.prof = s->d_prof; w.npol = s->d_npol; w.tAB = (double *)s->tAB;
+    Inputs<float> in;
+    in.x0 = (const float *)x0; in.yref = (const float *)yref; in.yref_e = (const float *)yref_e;
+    in.x_init = cold ? nullptr : (const float *)x_init; in.u_init = cold ? nullptr : (const float *)u_init;
+    in.yref_bcast = bcast;
+    Outputs<float> out;
+    out.u0 = (float *)u0; out.x_out = (float *)x_out; out.u_out = (float *)u_out; out.status = status;
+    TeamWork<double> tw;
+    tw.tLM = (double *)s->LM; tw.tIV = (double *)s->iv;
+    tw.tP = c.polish_ckpt > 0 ? (double *)s->tP : nullptr;
+    int tpw = s->team_tpw;
+    if (tpw == 0) tpw = (B >= 2048) ? 4 : (B >= 512 ? 2 : 1);
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
+    return launch_split<float>(s, c, w, in, out, tw, B, tpw, st);
+}
 
 template <class T>
 static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
@@ -431,38 +514,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                            s->cfg.qp_polish_passes > 0 && s->cfg.qp_polish_mu >= s->cfg.qp_mu0 &&
                            s->cfg.sim_num_steps <= AS_MAX_STEPS && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
         if constexpr (F64) {
-            if (split) {
-                WorkList wl;
-                wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
-                const int nlist = std::min((B + 3) / 4, 128);
-                const bool traj = x_out != nullptr || u_out != nullptr;
-                int occ_as = s->team_occ;
-                // two waves per SIMD need >= 2048 waves; the per-stage variant spills inside its sweeps at 256 registers
-                // (measured slower than one wave per SIMD at every batch size), so only the shared variant takes it
-                if (occ_as == 0) occ_as = (c.shared && (B + tpw - 1) / tpw >= 2048) ? 2 : 1;
-                // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD,
-                // 20 KB at two) holds the factors of the first stages; the team stride stays 192 B past a multiple of
-                // the 256-B bank row (24 doubles mod 32)
-                const int base_as = c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
-                const int per_team = (occ_as == 2 ? 20480 : 40960) / 4 / (int)sizeof(double);
-                int lstg = occ_as == 2 ? 0 : std::max(0, std::min(s->cfg.N, (per_team - base_as - 31) / AS_LM_ROWS));   // the two-waves build carries no cache
-                if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
-                int lds_stride = base_as + lstg * AS_LM_ROWS;
-                lds_stride += (24 - lds_stride % 32 + 32) % 32;
-                const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
-#define NMPC_LAUNCH_AS(SH_, TR_) do { if (occ_as == 2) hipLaunchKernelGGL((k_team_as<SH_, TR_, 2>), tgrid, tblock, lds_as, st, (const Consts<double> *)s->d_consts, w, in, out, tw, wl, B, tpw, lds_stride, lstg); \
-                                      else hipLaunchKernelGGL((k_team_as<SH_, TR_, 1>), tgrid, tblock, lds_as, st, (const Consts<double> *)s->d_consts, w, in, out, tw, wl, B, tpw, lds_stride, lstg); } while (0)
-                if (c.shared) { if (traj) NMPC_LAUNCH_AS(true, true); else NMPC_LAUNCH_AS(true, false); }
-                else { if (traj) NMPC_LAUNCH_AS(false, true); else NMPC_LAUNCH_AS(false, false); }
-                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-                if (c.shared) hipLaunchKernelGGL(k_team_ipm_list<true>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-                else hipLaunchKernelGGL(k_team_ipm_list<false>, dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-#undef NMPC_LAUNCH_AS
-                HIP_TRY(s, hipGetLastError());
-                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
-                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
-                return 0;
-            }
+            if (split) return launch_split<double>(s, c, w, in, out, tw, B, tpw, st);
         }
 #define NMPC_LAUNCH_TEAM(W_, SH_, MF_) hipLaunchKernelGGL((k_team_ipm<T, W_, SH_, MF_>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw)
         if (mf) {
@@ -503,6 +555,7 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
     if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "solve_batch: x_init and u_init must both be given or both be NULL");
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     hipStream_t st = (hipStream_t)hip_stream;
+    if (s->cfg.dtype == NMPC_DTYPE_F32IO) return launch_f32io(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
     int rc = s->cfg.dtype == NMPC_DTYPE_F64
                  ? launch<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st)
                  : launch<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);

@@ -178,8 +178,9 @@ struct Pair {
 // BATCH: read the LDS operands of the P*[B b A] products in fenced batches (1 wave per SIMD only)
 // SHARED: all stages use one (Ad, B, b) (cold start, NMPC_FLAG_SHARE_COLD_START) - compile time so
 // that the per-stage reload code and its address arithmetic do not exist in the shared variant
-template <class T, bool BATCH, bool SHARED, bool MF>
-__device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out,
+// TO: element type of the caller's output arrays (float for NMPC_DTYPE_F32IO: FP64 arithmetic on FP32 buffers)
+template <class T, bool BATCH, bool SHARED, bool MF, class TO = T>
+__device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<TO> &out,
                                          const TeamWork<T> &tw, int B, int tpw, T *smem, long long t_entry = 0,
                                          bool lds_prefilled = false, int inst_ov = -2, bool resume = false)
 {
@@ -1618,8 +1619,9 @@ __device__ __forceinline__ void vde_col_rt(const Consts<T> &c, const Jac<T> &J, 
     }
 }
 
-template <class T>
-__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, int B, int tpw,
+// TI: element type of the caller's input arrays (float for NMPC_DTYPE_F32IO)
+template <class T, class TI = T>
+__device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<TI> &in, int B, int tpw,
                                              T *smem = nullptr, int inst_ov = -2)
 {
     // smem != null (fused launch) and a shared cold-start linearisation: the stage matrices go straight
@@ -1633,11 +1635,11 @@ __device__ __forceinline__ void team_prepare(const Consts<T> &c, const Work<T> &
     const int N = c.N;
     const int XLR = (N + 1) * NX, ULR = N * NU, QRR = N * QR_ROWS + NX;
     const bool warm = in.x_init != nullptr && in.u_init != nullptr;
-    const T *x0 = in.x0 + (size_t)inst * NX;
-    const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
-    const T *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
-    const T *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : nullptr;
-    const T *ui = warm ? in.u_init + (size_t)inst * N * NU : nullptr;
+    const TI *x0 = in.x0 + (size_t)inst * NX;
+    const TI *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
+    const TI *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
+    const TI *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : nullptr;
+    const TI *ui = warm ? in.u_init + (size_t)inst * N * NU : nullptr;
     const T Wqr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.Wq[i] : v; return v; }();
     const T WqNr = [&] { T v = 0; NMPC_UNROLL for (int i = 0; i < NX; i++) v = (i == rr) ? c.WqN[i] : v; return v; }();
     const T Wrj = sel4(c.Wr, j);

@@ -75,15 +75,16 @@ struct WorkList {
     int *list;      // [Bp] instance indices
 };
 
-template <bool SHARED, bool TRAJ, bool LDSC>
-__device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<double> &in,
-                                        const Outputs<double> &out, const TeamWork<double> &tw, const WorkList &wl,
+template <bool SHARED, bool TRAJ, bool LDSC, class TI>
+__device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
+                                        const Outputs<TI> &out, const TeamWork<double> &tw, const WorkList &wl,
                                         int B, int tpw, double *smem, int lds_stride, int lstg)
 {
     // lds_stride: doubles of LDS per team (carve below + the stage cache); lstg: the factors of stages 0 .. lstg-1 -
     // written last by the backward sweep and read first by the forward sweep - stay in LDS and never reach HBM
     // SHARED: cold start with one linearisation for all stages (x_k = x0, u_k = 0 folded at compile time)
     // TRAJ:   the caller wants x_out / u_out: the forward sweep also leaves xhat_k and every candidate input
+    // TI:     element type of the caller's arrays: double, or float (NMPC_DTYPE_F32IO: the arithmetic stays FP64)
     // LDSC:   the build carries the LDS stage cache (one wave per SIMD: 40 KB of LDS per wave); without it
     //         lstg must be 0 and the code is the plain HBM-scratch form (two waves per SIMD: 20 KB per wave)
     using T = double;
@@ -107,11 +108,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sD = S + A_D, *sh = S + A_H, *sXh = S + A_XH;
     T *sRed = S + A_RED, *sEv = S + A_EV, *sLM = S + A_LM;
     const bool warm = !SHARED && in.x_init != nullptr && in.u_init != nullptr;
-    const T *x0p = in.x0 + (size_t)inst * NX;
-    const T *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
-    const T *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
-    const T *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : x0p;
-    const T *ui = warm ? in.u_init + (size_t)inst * N * NU : x0p;
+    const TI *x0p = in.x0 + (size_t)inst * NX;
+    const TI *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
+    const TI *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
+    const TI *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : x0p;
+    const TI *ui = warm ? in.u_init + (size_t)inst * N * NU : x0p;
     T *const tLM_own = tw.tLM + (size_t)winst * N * TLM_ROWS, *const tIV_own = tw.tIV + (size_t)winst * N * IV_ROWS;
     const int ckpt = c.polish_ckpt;
     T *const tP_own = tw.tP ? tw.tP + (size_t)winst * (ckpt + 1) * TP_ROWS : nullptr;
@@ -127,7 +128,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     // ---- per-lane constants, taken into vector registers once
     T dt_v = c.dt, kkt_v = c.kkt_tol;
     asm volatile("" : "+v"(dt_v), "+v"(kkt_v));
-    const T x0r = x0p[rr];
+    const T x0r = (T)x0p[rr];
     // (c lives in device memory: an entry picked by a lane-dependent index is ONE vector load, where the by-value
     // constant block cost a 13-way select chain per entry and 190 scalar registers - 584 of the 1413 instructions
     // in front of the first MFMA were scalar-register spill traffic)
@@ -160,9 +161,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const bool mine = r < CH && k < Ns;
                 const int kk = mine ? k : 0;
                 T xs[NX], us[NU], xn1[NX];
-                NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (warm && kk > 0) ? xi[(size_t)kk * NX + i] : x0p[i];   // stage 0 is pinned to x0
-                NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = warm ? ui[(size_t)kk * NU + i] : T(0);
-                NMPC_UNROLL for (int i = 0; i < NX; i++) xn1[i] = warm ? xi[(size_t)(kk + 1) * NX + i] : x0p[i];
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = (T)((warm && kk > 0) ? xi[(size_t)kk * NX + i] : x0p[i]);   // stage 0 is pinned to x0
+                NMPC_UNROLL for (int i = 0; i < NU; i++) us[i] = warm ? (T)ui[(size_t)kk * NU + i] : T(0);
+                NMPC_UNROLL for (int i = 0; i < NX; i++) xn1[i] = (T)(warm ? xi[(size_t)(kk + 1) * NX + i] : x0p[i]);
                 T *ev = sEv + (SHARED ? 0 : (r < CH ? r : 0) * AS_EV);
                 for (int st = 0; st < nsteps; st++) {
                     T f1[NX], xm[NX], f2[NX];
@@ -263,8 +264,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         NMPC_WSYNC();
     };
     // linearisation point of stage k, natural row rr / input comp (cold start: x_k = x0, u_k = 0)
-    auto xlin = [&](int k) -> T { return (warm && k > 0) ? xi[(size_t)k * NX + rr] : x0r; };
-    auto ulin = [&](int k, int comp) -> T { return warm ? ui[(size_t)k * NU + comp] : T(0); };
+    auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
+    auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
 
     int status = 0, npol = 0, pass_in_attempt = 0;
     int k_top = N - 1;       // highest stage this team's next backward sweep has to refactorise
@@ -323,7 +324,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             T Pt[4][4];
             if (ks == N - 1) {
                 // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
-                sh[r] = WqN_r * (xlin(N) - ye[rr]);
+                sh[r] = WqN_r * (xlin(N) - (T)ye[rr]);
                 NMPC_WSYNC();
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
@@ -344,7 +345,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             // scalars of a stage are fetched one stage ahead (global loads stay in flight over the stage):
             // reference row rr, reference / linearisation input of component j (pins) or a (no pins), pin code
             const int cu = PINS ? j : ta;
-            T n_yx = yr[(size_t)ks * NY + rr], n_yu = yr[(size_t)ks * NY + NX + cu];
+            T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + cu];
             T n_xl = xlin(ks), n_ul = ulin(ks, cu);
             T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
             auto stage = [&](int k, auto last_tag, auto lds_tag) {
@@ -361,7 +362,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const T q_r = Wq_r * (n_xl - n_yx);
                 asm volatile("" : "+v"(rk));             // (q_r passes through LDS, which rounds it in both variants)
                 if (!LAST) {
-                    n_yx = yr[(size_t)(k - 1) * NY + rr]; n_yu = yr[(size_t)(k - 1) * NY + NX + cu];
+                    n_yx = (T)yr[(size_t)(k - 1) * NY + rr]; n_yu = (T)yr[(size_t)(k - 1) * NY + NX + cu];
                     n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
                     if (PINS) n_pc = tIV[(k - 1) * IV_ROWS + 16 + j];
                 }
@@ -603,7 +604,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         const T *lmn = tLM + k * TLM_ROWS;
                         T cG[5];
                         NMPC_UNROLL for (int g5 = 0; g5 < 5; g5++) cG[g5] = lmn[TLM_G + g5 * 16 + r];
-                        T rka = Wr_a * (ul - yr[(size_t)k * NY + NX + ta]);
+                        T rka = Wr_a * (ul - (T)yr[(size_t)k * NY + NX + ta]);
                         asm volatile("" : "+v"(rka));
                         const T uf = (tc == 0 && !pin_here) ? ue : T(0);                    // mask u
                         T g = mfma44(cG[4], uf, T(0));
@@ -699,7 +700,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         if (out.status) out.status[inst] = status;
         w.iters[inst] = 0; w.status[inst] = status; w.npol[inst] = accepted ? npol : -npol;
     }
-    if (tc == 0) out.u0[(size_t)inst * NU + ta] = accepted ? ulin(0, ta) + u0_cand : T(0);   // controller.py:448-452
+    if (tc == 0) out.u0[(size_t)inst * NU + ta] = (TI)(accepted ? ulin(0, ta) + u0_cand : T(0));   // controller.py:448-452
     if (TRAJ) {
         constexpr int CH = 8;
         for (int k0 = 0; k0 <= N; k0 += CH) {
@@ -715,8 +716,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const int k = k0 + i;
                 if (k <= N) {
                     if (out.x_out && rowl)
-                        out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = accepted ? xlv[i] + (k > 0 ? xhv[i] : T(0)) : x0r;
-                    if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = accepted ? ulv[i] + uv[i] : T(0);
+                        out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = (TI)(accepted ? xlv[i] + (k > 0 ? xhv[i] : T(0)) : x0r);
+                    if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = (TI)(accepted ? ulv[i] + uv[i] : T(0));
                 }
             }
         }

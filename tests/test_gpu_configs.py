@@ -210,3 +210,53 @@ def test_solver_first_then_torch_share_one_hip_runtime():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                        cwd=str(Path(__file__).resolve().parent.parent))
     assert r.returncode == 0 and "ok" in r.stdout, r.stderr + r.stdout
+
+
+def test_config3_f32io_batch_65536_fp64_arithmetic_on_fp32_buffers():
+    """NMPC_DTYPE_F32IO: config 3's buffers (FP32 x0 / yref in, FP32 u0 / trajectories out: half the compulsory
+    bytes) with the FP64 tile kernels doing the arithmetic.  The only error left is the float rounding of the
+    OUTPUT: |u0 - oracle| <= 1e-6 N on the same float-representable inputs (thrusts O(1) N, float ulp 1.2e-7 rel.)
+    -- inside BASELINE.json's 1e-6 relative target, which the all-FP32 arithmetic (5e-5 above) is not."""
+    B = 65536
+    s = make_solver(dtype=_lib.DTYPE_F32IO, max_batch=B)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(B, 1, **NEAR_HOVER).astype(np.float32).astype(np.float64)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    assert (out["status"] == 0).all()
+    lbu, ubu = np.array(s.config.lbu), np.array(s.config.ubu)
+    assert (out["u"] >= lbu - 1e-6).all() and (out["u"] <= ubu + 1e-6).all()
+    np.testing.assert_array_equal(out["x"][:, 0], x0)
+    perm = np.random.default_rng(1).permutation(B)
+    out_p = s.solve_batch(x0[perm], yref, ye)
+    np.testing.assert_array_equal(out_p["u0"], out["u0"][perm])
+    idx = np.arange(0, B, 64)
+    ref = O.solve_batch(O.default_config(qp_gamma=0.0, qp_polish=1), x0[idx], yref.astype(np.float32).astype(np.float64),
+                        ye.astype(np.float32).astype(np.float64), want_traj=True)
+    assert np.abs(out["u0"][idx] - ref["u0"]).max() < 1e-6
+    assert np.abs(out["x"][idx] - ref["x"]).max() < 2e-6
+    assert s.stats()["n_polished"] >= B - 8                    # (nearly) every instance ends on an exact active-set solution
+
+
+def test_f32io_warm_start_aggressive_and_work_list():
+    """F32IO through the per-stage variant (warm start) and through the second launch (aggressive set: some
+    instances need interior-point iterations), against the FP64 solver on the same float-representable inputs."""
+    B = 512
+    f = lambda a: np.asarray(a).astype(np.float32).astype(np.float64)    # noqa: E731
+    s32 = make_solver(dtype=_lib.DTYPE_F32IO, max_batch=B)
+    s64 = make_solver(max_batch=B)
+    yref, ye = hover(s64.config)
+    yref, ye = f(yref), f(ye)
+    x0 = f(sample_x0(B, 0, **AGGRESSIVE))
+    a, b = s32.solve_batch(x0, yref, ye, want_traj=True), s64.solve_batch(x0, yref, ye, want_traj=True)
+    np.testing.assert_array_equal(a["status"], b["status"])
+    assert s32.stats()["iter_max"] > 0                          # the work-list launch really ran
+    np.testing.assert_allclose(a["u0"], b["u0"], rtol=0, atol=1e-6)
+    x1 = f(x0 + np.random.default_rng(3).normal(0, 0.01, x0.shape))
+    a2 = s32.solve_batch(x1, yref, ye, x_init=a["x"], u_init=a["u"], want_traj=True)
+    b2 = s64.solve_batch(x1, yref, ye, x_init=a["x"], u_init=a["u"], want_traj=True)     # same (float-valued) warm start
+    np.testing.assert_array_equal(a2["status"], b2["status"])
+    np.testing.assert_allclose(a2["u0"], b2["u0"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(a2["x"], b2["x"], rtol=0, atol=2e-6)
+    from rotors_mpc_controller_amd.solver import NmpcError
+    with pytest.raises(NmpcError):
+        make_solver(dtype=_lib.DTYPE_F32IO, qp_polish=0)            # default path only
