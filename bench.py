@@ -210,6 +210,8 @@ def main() -> None:
     ap.add_argument("--no-polish", action="store_true", help="plain interior point iteration (qp_polish = 0)")
     ap.add_argument("--condensed", action="store_true", help="partial-condensing kernel (NMPC_FLAG_CONDENSED_QP)")
     ap.add_argument("--polish-ckpt", type=int, default=None, help="override nmpc_config.qp_polish_ckpt")
+    ap.add_argument("--polish-passes", type=int, default=None, help="override nmpc_config.qp_polish_passes (passes per attempt)")
+    ap.add_argument("--polish-budget", type=int, default=None, help="override nmpc_config.qp_polish_budget (passes in total)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
 
@@ -251,6 +253,10 @@ def main() -> None:
         cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
     if args.polish_ckpt is not None:
         cfg.update(qp_polish_ckpt=args.polish_ckpt)
+    if args.polish_passes is not None:
+        cfg.update(qp_polish_passes=args.polish_passes)
+    if args.polish_budget is not None:
+        cfg.update(qp_polish_budget=args.polish_budget)
     if args.no_polish:
         cfg.update(qp_polish=0)
     if args.condensed:

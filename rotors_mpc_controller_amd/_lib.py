@@ -78,11 +78,11 @@ EXPORTS = (
 
 def build(force: bool = False) -> Path:
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    srcs = [CSRC / n for n in ("nmpc_capi.hip", "nmpc_lane.hpp", "nmpc_ipm.hpp", "nmpc_team.hpp", "nmpc_team_as.hpp", "nmpc_cond.hpp", "nmpc_aux.hpp", "nmpc_consts.hpp")]
+    srcs = sorted(CSRC.glob("*.hip")) + sorted(CSRC.glob("*.hpp")) + [CSRC / "Makefile"]
     srcs.append(_PKG.parent / "include" / "rotors_nmpc.h")
     stale = (not LIB_PATH.exists()) or any(p.stat().st_mtime > LIB_PATH.stat().st_mtime for p in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", str(CSRC)] + (["-B"] if force else []))
+        subprocess.check_call(["make", "-j2", "-C", str(CSRC)] + (["-B"] if force else []))
     return LIB_PATH
 
 

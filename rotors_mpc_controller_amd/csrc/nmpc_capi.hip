@@ -21,6 +21,7 @@
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
 #include "nmpc_team_as.hpp"
+#include "nmpc_as_launch.hpp"
 #include "nmpc_cond.hpp"
 #include "nmpc_aux.hpp"
 #include "nmpc_consts.hpp"
@@ -75,19 +76,6 @@ __global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inpu
         __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
     }
     team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry, SHARED && fused != 0);
-}
-
-// default FP64 path, first launch: preparation + the first active-set attempt (nmpc_team_as.hpp).
-// OCC = waves per SIMD the register allocation allows: 2 (256 registers) pays once the batch supplies two waves
-// per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
-template <bool SHARED, bool TRAJ, int OCC, class TI>
-__global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
-                                                     TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    // the constant block is read from device memory (uploaded at create): scalar loads on demand for uniform entries,
-    // one vector load for a per-lane entry
-    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg);
 }
 
 // default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
@@ -397,15 +385,11 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     int lds_stride = base_as + lstg * AS_LM_ROWS;
     lds_stride += (24 - lds_stride % 32 + 32) % 32;
     const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
-    const Consts<double> *cp = (const Consts<double> *)s->d_consts;
-#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), tgrid, tblock, lds_as, st, cp, w, in, out, tw, wl, B, tpw, lds_stride, lstg)
-    if (c.shared) {
-        if (occ_as == 2) { if (traj) NMPC_LAUNCH_AS(true, true, 2); else NMPC_LAUNCH_AS(true, false, 2); }
-        else { if (traj) NMPC_LAUNCH_AS(true, true, 1); else NMPC_LAUNCH_AS(true, false, 1); }
-    } else {
-        if (traj) NMPC_LAUNCH_AS(false, true, 1); else NMPC_LAUNCH_AS(false, false, 1);
-    }
-#undef NMPC_LAUNCH_AS
+    AsLaunch al;
+    al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
+    al.lds_stride = lds_stride; al.lstg = lstg; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
+    al.lds_bytes = lds_as; al.stream = st;
+    HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
     if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
     else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
