@@ -260,3 +260,20 @@ def test_f32io_warm_start_aggressive_and_work_list():
     from rotors_mpc_controller_amd.solver import NmpcError
     with pytest.raises(NmpcError):
         make_solver(dtype=_lib.DTYPE_F32IO, qp_polish=0)            # default path only
+
+
+def test_config5_gpu_uncondensed_agrees_with_block_120_condensing():
+    """Config 5's "both blockings must agree" (SURVEY 8d): the GPU's internal blocking (uncondensed Riccati, plain
+    interior point here for a like-for-like comparison) against the oracle's partial condensing with acados' own
+    blocking for N = 600 (5 blocks of 120 stages), on two instances: |u0| difference <= 1e-9."""
+    N = 600
+    s = make_solver(N=N, max_batch=8, qp_polish=0)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(1024, 5, **NEAR_HOVER)[:2]
+    out = s.solve_batch(x0, yref, ye)
+    rc = O.solve_batch(O.default_config(N=N, qp_gamma=0.0, qp_polish=0, qp_cond_N=5), x0, yref, ye, nthreads=2)
+    assert (out["status"] == 0).all() and (rc["status"] == 0).all()
+    np.testing.assert_allclose(out["u0"], rc["u0"], rtol=0, atol=1e-9)
+    # and the default path (active-set passes by the long-horizon policy 8 / 16) lands on the same command
+    sd = make_solver(N=N, max_batch=8)
+    np.testing.assert_allclose(sd.solve_batch(x0, yref, ye)["u0"], rc["u0"], rtol=0, atol=1e-8)

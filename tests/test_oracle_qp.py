@@ -247,3 +247,28 @@ def test_polish_off_is_the_plain_ipm_and_polish_on_needs_fewer_kkt_rounds():
     pol = O.solve_batch(O.default_config(qp_polish=1), x0, yref, ye)
     assert plain["iters"].min() >= 5 and pol["iters"].mean() < 0.5
     assert np.abs(plain["u0"] - pol["u0"]).max() < 1e-4          # same solution up to the IPM's accuracy
+
+
+def test_config5_block_120_condensing_agrees_with_the_uncondensed_qp():
+    """N = 600 with acados' own blocking (qp_solver_cond_N = min(N,5) = 5 blocks of 120 stages,
+    480 block inputs, controller.py:184) against the uncondensed Riccati solve of the same QP (U8: condensing is a
+    reformulation).  u0 agrees to 1e-9; the trajectories to 1e-6 (both are interior-point iterates stopped at
+    mu <= 1e-11: weakly active bounds keep a slack of that order).  Also the measurement VERDICT r1 #8 asks for:
+    the block-120 form costs ~40x the uncondensed one on the same core (dense 480x480 Cholesky per block and
+    iteration against 600 factorisations of 4x4) -- the reason the GPU path does not condense."""
+    import time
+    N = 600
+    yref, ye = O.hover_yref(O.default_config(N=N))
+    x0 = sample_x0(1024, 5, **NEAR_HOVER)[:2]
+    t = time.perf_counter()
+    ru = O.solve_batch(O.default_config(N=N, qp_gamma=0.0, qp_polish=0, qp_cond_N=0), x0, yref, ye, want_traj=True, nthreads=2)
+    tu = time.perf_counter() - t
+    t = time.perf_counter()
+    rc = O.solve_batch(O.default_config(N=N, qp_gamma=0.0, qp_polish=0, qp_cond_N=5), x0, yref, ye, want_traj=True, nthreads=2)
+    tc = time.perf_counter() - t
+    assert (ru["status"] == 0).all() and (rc["status"] == 0).all()
+    np.testing.assert_array_equal(rc["iters"], ru["iters"])               # same iteration path on the reformulated QP
+    np.testing.assert_allclose(rc["u0"], ru["u0"], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(rc["u"], ru["u"], rtol=0, atol=1e-6)
+    np.testing.assert_allclose(rc["x"], ru["x"], rtol=0, atol=1e-6)
+    assert tc > 5 * tu, (tc, tu)
