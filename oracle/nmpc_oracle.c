@@ -64,8 +64,8 @@ void orc_default_config(orc_config *c)
     c->qp_gamma = 0.0;   /* optional safeguard; the HIP kernels do not implement it */
     c->qp_polish = 0;
     c->qp_polish_mu = 1.0;      /* >= mu0: the first attempt is a pure active-set solve from 'all free' */
-    c->qp_polish_passes = 5;
-    c->qp_polish_budget = 8;
+    c->qp_polish_passes = 8;   /* = the GPU library's default attempt policy (nmpc_create) */
+    c->qp_polish_budget = 16;
 }
 
 /* ------------------------------------------------------------------------------------ */

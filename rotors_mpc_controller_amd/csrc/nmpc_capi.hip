@@ -206,7 +206,7 @@ void nmpc_default_config(nmpc_config *c)
     c->max_batch = 4096;
     c->flags = NMPC_FLAG_SHARE_COLD_START | NMPC_FLAG_TEAM_MAPPING;
     c->qp_polish = 1;
-    c->qp_polish_passes = 0;   // 0 = by horizon (nmpc_create): 5 passes per attempt / 8 in total up to N = 128, 8 / 16 beyond
+    c->qp_polish_passes = 0;   // 0 = the measured default (nmpc_create): 8 passes per attempt, 16 in total
     c->qp_polish_budget = 0;
     c->qp_polish_mu = 1.0;
     c->qp_polish_ckpt = 12;
@@ -293,12 +293,13 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (hipSetDevice(cfg->device) != hipSuccess) return bad("nmpc_create: hipSetDevice failed");
     auto *s = new nmpc_solver();
     s->cfg = *cfg;
-    // Attempt policy of the active-set passes, by horizon when left at 0.  Measured on MI355X (near-hover set): up to N = 120
-    // every instance is settled within 5 passes and the two settings coincide; at N = 250 five passes per attempt leave a
-    // few instances to the interior-point iteration, which then sets the time of the whole batch (14.9 ms against 3.5 ms with
-    // 8 / 16); at N = 600 8 / 16 is the fastest setting with the passes on (39.6 ms; 5 / 8 43.3 ms, 12 / 24 42.8 ms).
-    if (s->cfg.qp_polish_passes <= 0) s->cfg.qp_polish_passes = cfg->N > 128 ? 8 : 5;
-    if (s->cfg.qp_polish_budget <= 0) s->cfg.qp_polish_budget = cfg->N > 128 ? 16 : 8;
+    // Attempt policy of the active-set passes when left at 0: 8 passes per attempt, 16 in total.  An extra pass costs the
+    // instance ~10-25 us in the active-set kernel, a hand-over to the interior-point iteration ~0.5 ms for the whole batch
+    // (measured on MI355X, B = 4096: aggressive set 6.6 M solves/s with 5 / 8 - 31 instances in the second launch - against
+    // 18.7 M with 8 / 16, none; N = 250 near-hover 14.9 ms against 3.5 ms; N = 600 43.3 ms against 39.6 ms; more than 8 / 16
+    // changed nothing or lost: N = 600 12 / 24 42.8 ms).  The near-hover N = 20 set needs 3 passes at most either way.
+    if (s->cfg.qp_polish_passes <= 0) s->cfg.qp_polish_passes = 8;
+    if (s->cfg.qp_polish_budget <= 0) s->cfg.qp_polish_budget = 16;
     if (cfg->dtype == NMPC_DTYPE_F32) {
         // FP32 cannot resolve the FP64 stopping thresholds; floors found by sweeping the
         // tolerance against the FP64 oracle (max |u0| error 2.4e-4 .. 7.9e-4 N at these values)
@@ -373,7 +374,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);
     WorkList wl;
     wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
-    const int nlist = std::min((B + 3) / 4, 128);
+    const int nlist = std::min((B + 3) / 4, 64);      // usually empty: keep the launch small (each workgroup strides over the list)
     const bool traj = out.x_out != nullptr || out.u_out != nullptr;
     const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
     int occ_as = s->team_occ;

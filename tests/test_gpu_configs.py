@@ -238,15 +238,17 @@ def test_config3_f32io_batch_65536_fp64_arithmetic_on_fp32_buffers():
 
 
 def test_f32io_warm_start_aggressive_and_work_list():
-    """F32IO through the per-stage variant (warm start) and through the second launch (aggressive set: some
-    instances need interior-point iterations), against the FP64 solver on the same float-representable inputs."""
+    """F32IO through the per-stage variant (warm start) and through the second launch (wild set - bounds active in
+    most stages: some instances exhaust their active-set passes and need interior-point iterations), against the FP64
+    solver on the same float-representable inputs."""
     B = 512
     f = lambda a: np.asarray(a).astype(np.float32).astype(np.float64)    # noqa: E731
     s32 = make_solver(dtype=_lib.DTYPE_F32IO, max_batch=B)
     s64 = make_solver(max_batch=B)
     yref, ye = hover(s64.config)
     yref, ye = f(yref), f(ye)
-    x0 = f(sample_x0(B, 0, **AGGRESSIVE))
+    x0 = f(np.concatenate([sample_x0(B // 2, 0, **AGGRESSIVE),
+                           sample_x0(B // 2, 2, sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)]))
     a, b = s32.solve_batch(x0, yref, ye, want_traj=True), s64.solve_batch(x0, yref, ye, want_traj=True)
     np.testing.assert_array_equal(a["status"], b["status"])
     assert s32.stats()["iter_max"] > 0                          # the work-list launch really ran

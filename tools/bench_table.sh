@@ -1,7 +1,7 @@
 #!/bin/bash
 # All rows of DESIGN.md section 5 in one GPU call.
 row() {
-  python bench.py --no-cpu-baseline "$@" > gpurun_out/bench_q.json 2>gpurun_out/bench_q.err || { echo "[$*] FAILED"; tail -3 gpurun_out/bench_q.err; return; }
+  python bench.py --no-cpu-baseline --no-secondary "$@" > gpurun_out/bench_q.json 2>gpurun_out/bench_q.err || { echo "[$*] FAILED"; tail -3 gpurun_out/bench_q.err; return; }
   python - "$*" <<'PY'
 import json, sys
 d = json.load(open("gpurun_out/bench_q.json"))
@@ -19,6 +19,7 @@ row --mapping lane --steps 5 --warmup 1
 row --batch 1024
 row --batch 16384
 row --batch 65536 --dtype f32
+row --batch 65536 --dtype f32io
 row --batch 65536
 row --batch 65536 --no-share
 row --batch 1024 --horizon 600 --steps 5 --warmup 1
