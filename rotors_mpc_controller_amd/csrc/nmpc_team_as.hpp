@@ -481,11 +481,26 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         Lf[lidx(i, jj)] = a * rd;
                     }
                 }
-                // Y = L^-T as a tile (lane (a,c) holds (L^-1 e_a)_c), M = L^-1 X = Y' X
-                T ea[NU];
-                NMPC_UNROLL for (int i = 0; i < NU; i++) ea[i] = (i == ta) ? T(1) : T(0);
-                l_solve(Lf, ea);
-                const T Y = sel4(ea, tc);
+                // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the 4x4 triangle in closed form (the
+                // diagonal of Lf already holds 1 / L_ii) and one select by the lane's (c,a): straight-line code - a
+                // forward substitution on the unit vector e_a, as the general kernel does it, compiles to lane-divergent
+                // branches that cut the stage's scheduling region
+                T Y;
+                {
+                    const T i00 = Lf[lidx(0, 0)], i11 = Lf[lidx(1, 1)], i22 = Lf[lidx(2, 2)], i33 = Lf[lidx(3, 3)];
+                    const T l10 = Lf[lidx(1, 0)], l20 = Lf[lidx(2, 0)], l21 = Lf[lidx(2, 1)];
+                    const T l30 = Lf[lidx(3, 0)], l31 = Lf[lidx(3, 1)], l32 = Lf[lidx(3, 2)];
+                    const T i10 = -i11 * (l10 * i00);
+                    const T i21 = -i22 * (l21 * i11);
+                    const T i32 = -i33 * (l32 * i22);
+                    const T i20 = -i22 * (l20 * i00 + l21 * i10);
+                    const T i31 = -i33 * (l31 * i11 + l32 * i21);
+                    const T i30 = -i33 * (l30 * i00 + l31 * i10 + l32 * i20);
+                    const int e = tc * 4 + ta;           // (row c, column a) of L^-1
+                    Y = T(0);
+                    Y = e == 0 ? i00 : Y;  Y = e == 4 ? i10 : Y;  Y = e == 5 ? i11 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
+                    Y = e == 10 ? i22 : Y; Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y; Y = e == 15 ? i33 : Y;
+                }
                 T M[4];
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                     M[jt] = mfma44(Y, X[jt], T(0));
