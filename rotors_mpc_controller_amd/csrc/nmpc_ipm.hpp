@@ -90,7 +90,7 @@ NMPC_HD void lane_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> 
         NMPC_UNROLL for (int i = 0; i < NX; i++)
             NMPC_ST(w.bv, k * NX + i, xn[i] - NMPC_LD(w.xl, (k + 1) * NX + i));
         if (w.tAB) {   // row-major per-instance copy for the team kernel (nmpc_team.hpp)
-            T *a = w.tAB + ((size_t)lane * Ns + k) * 176;
+            T *a = w.tAB + ((size_t)lane * Ns + k) * TAB_ROWS;
             NMPC_UNROLL for (int i = 0; i < NX; i++) {
                 NMPC_UNROLL for (int cc = 0; cc < 8; cc++) a[i * 8 + cc] = (cc < NZ && i < ad_rows(cc)) ? S[cc][i] : T(0);
                 NMPC_UNROLL for (int j = 0; j < NU; j++) a[104 + i * NU + j] = S[7 + j][i];

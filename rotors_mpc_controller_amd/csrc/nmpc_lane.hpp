@@ -64,6 +64,8 @@ struct Consts {
     T polish_mu, kkt_tol;   // kkt_tol: relative acceptance tolerance of the active-set KKT check
 };
 
+constexpr int TAB_ROWS = 192;       // doubles per stage of the team kernels' per-instance stage block tAB
+
 // SoA workspace: row r of an array is the contiguous run [r*Bp, r*Bp + Bp)
 template <class T>
 struct Work {
@@ -78,7 +80,7 @@ struct Work {
     int32_t *iters;   // [Bp]
     int32_t *status;  // [Bp]
     int32_t *npol;    // [Bp] active-set passes spent (team kernel), or null
-    T *tAB;           // [B][Ns][176] per-instance copy of (Ad rows | B rows | b) for the team kernel, or null
+    T *tAB;           // [B][Ns][TAB_ROWS] per-instance copy of (Ad rows | B rows | b) for the team kernel, or null
     long long *prof;  // [8][Bp] per-sweep time stamps, NMPC_PROFILE builds only (else null)
 };
 

@@ -41,7 +41,7 @@ constexpr int TLM_ROWS = 240;      // M (52) | L (10) | m (4) | xhat of the poli
                                    // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16) |
                                    // stages with pins: (B'Pbar Abar)^T unmasked (64) | (B'PB)^T (16)
 constexpr int TLM_MT = 80, TLM_Z = 144, TLM_G = 160;
-constexpr int TAB_ROWS = 176;       // 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad
+// TAB_ROWS (nmpc_lane.hpp): 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad here; 12 tiles x 16 in the active-set kernel
 constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
 constexpr int TP_ROWS = 256;        // per stage: 13 x 14 (VALU form) or 16 tiles x 16 lanes (MFMA form)
 // LDS carve per team, in elements of T

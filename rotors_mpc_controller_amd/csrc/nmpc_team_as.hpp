@@ -35,7 +35,7 @@
 namespace nmpc {
 
 constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
-constexpr int AS_EV = 32;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2
+constexpr int AS_EV = 48;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2 | [32..44] b_k
 constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 // LDS carve per team, in doubles
@@ -49,8 +49,8 @@ constexpr int A_XH = A_H + 16;       // [16]
 constexpr int A_RED = A_XH + 16;     // [32]     small reductions
 constexpr int A_EV = A_RED + 40;     // evaluation points of the linearisation
 // team strides 2752 B / 4544 B = 192 B past a multiple of the 256-B bank row (see TEAM_LDS in nmpc_team.hpp)
-constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 344
-constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 568
+constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 360
+constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 696
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
@@ -180,8 +180,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     if (SHARED) {
                         NMPC_UNROLL for (int i = 0; i < NX; i++) sbv[i] = xs[i] - xn1[i];
                     } else {
-                        T *a = tAB + (size_t)k * TAB_ROWS + 156;
-                        NMPC_UNROLL for (int i = 0; i < NX; i++) a[i] = xs[i] - xn1[i];
+                        NMPC_UNROLL for (int i = 0; i < NX; i++) ev[32 + i] = xs[i] - xn1[i];
                     }
                 }
             }
@@ -227,16 +226,30 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         }
                     }
                 }
-                NMPC_UNROLL for (int q = 0; q < PB; q++) {      // natural layout: Ad rows [13][8] | B rows [13][4] (b came from phase A)
+                NMPC_UNROLL for (int q = 0; q < PB; q++) {
                     const int k = k0 + e0 + q;
                     if (q == 0 || (e0 + q < CH && k < Ns)) {
-                        T *a = SHARED ? S : tAB + (size_t)k * TAB_ROWS;
-                        const int oA = SHARED ? A_AD : 0, oB = SHARED ? A_B : 104;
-                        NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                            if (natR[rt] >= 0) {
-                                a[oA + natR[rt] * 8 + tc] = Sx[q][rt][0];
-                                a[oA + natR[rt] * 8 + 4 + tc] = tc < 3 ? Sx[q][rt][1] : T(0);
-                                a[oB + natR[rt] * NU + tc] = Sx[q][rt][2];
+                        if (SHARED) {           // natural layout in LDS: Ad rows [13][8] | B rows [13][4] (b came from phase A)
+                            NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                                if (natR[rt] >= 0) {
+                                    S[A_AD + natR[rt] * 8 + tc] = Sx[q][rt][0];
+                                    S[A_AD + natR[rt] * 8 + 4 + tc] = tc < 3 ? Sx[q][rt][1] : T(0);
+                                    S[A_B + natR[rt] * NU + tc] = Sx[q][rt][2];
+                                }
+                            }
+                        } else {
+                            // per-stage linearisation: the 12 tiles of [Aq | Aw b | B] of the padded homogeneous form go to
+                            // the HBM scratch as tiles - tile (rt,ct) at [(3 rt + ct) 16 + r]: the factor sweep reads its
+                            // operand tiles back with one load each, the forward sweep reads them transposed by
+                            // swapping the lane index.  (Pad rows of the sensitivities are zero by construction; b_k
+                            // and the homogeneous 1 sit in column 15.)
+                            T *a = tAB + (size_t)k * TAB_ROWS + r;
+                            NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                                const T bq = ev[q][32 + (natR[rt] >= 0 ? natR[rt] : 0)];
+                                const T c15 = natR[rt] >= 0 ? bq : ((rt == 3 && ta == 3) ? T(1) : T(0));
+                                a[(rt * 3 + 0) * 16] = Sx[q][rt][0];
+                                a[(rt * 3 + 1) * 16] = tc < 3 ? Sx[q][rt][1] : c15;
+                                a[(rt * 3 + 2) * 16] = Sx[q][rt][2];
                             }
                         }
                     }
@@ -249,20 +262,14 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     __syncthreads();          // stage matrices (LDS, or this wave's own global rows) visible to every lane
     NMPC_STAMP(7)
 
-    // stage matrices of the per-stage variant: global -> registers one stage ahead -> LDS -> tiles
-    T pfs[13];
-    auto fetch_stage = [&](int k) {
-        const T *a = tAB + (size_t)k * TAB_ROWS;
-        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) pfs[cc] = a[rr * 8 + cc];
-        NMPC_UNROLL for (int i = 0; i < NU; i++) pfs[8 + i] = a[104 + rr * NU + i];
-        pfs[12] = a[156 + rr];
+    // stage tiles of the per-stage variant: HBM scratch -> registers, one stage ahead (lr = r: as stored; lr = 4c + a:
+    // every tile transposed)
+    T pfs[12];
+    auto fetch_stage = [&](int k, int lr) {
+        const T *a = tAB + (size_t)k * TAB_ROWS + lr;
+        NMPC_UNROLL for (int t = 0; t < 12; t++) pfs[t] = a[t * 16];
     };
-    auto put_stage = [&]() {
-        NMPC_UNROLL for (int cc = 0; cc < 8; cc++) sAd[r * 8 + cc] = pfs[cc];
-        NMPC_UNROLL for (int i = 0; i < NU; i++) sB[r * 4 + i] = pfs[8 + i];
-        sbv[r] = pfs[12];
-        NMPC_WSYNC();
-    };
+    const int rT = tc * 4 + ta;
     // linearisation point of stage k, natural row rr / input comp (cold start: x_k = x0, u_k = 0)
     auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
     auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
@@ -320,7 +327,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     Bt[kt] = real ? bb : T(0);
                 }
             };
-            if (SHARED) load_tiles(); else fetch_stage(ks);
+            if (SHARED) load_tiles(); else fetch_stage(ks, r);
             T Pt[4][4];
             if (ks == N - 1) {
                 // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
@@ -351,7 +358,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             auto stage = [&](int k, auto last_tag, auto lds_tag) {
                 constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
                 constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
-                if (!SHARED) { put_stage(); if (!LAST) fetch_stage(k - 1); load_tiles(); }
+                if (!SHARED) {
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
+                    if (!LAST) fetch_stage(k - 1, r);
+                }
                 T *lmk = tLM + k * TLM_ROWS;
                 const T ul = n_ul, pc = n_pc;
                 // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
@@ -565,7 +575,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     BT[it] = real ? bb : T(0);
                 }
             };
-            if (SHARED) load_tiles_T(); else fetch_stage(0);
+            if (SHARED) load_tiles_T(); else fetch_stage(0, rT);
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
             // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
@@ -589,7 +599,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 o.z = lmn[64 + r];
             };
             auto stageB = [&](int k, const Ops &o) {
-                if (!SHARED) { put_stage(); if (k + 1 < N) fetch_stage(k + 1); load_tiles_T(); }
+                if (!SHARED) {
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = pfs[it * 3]; AT3[it] = pfs[it * 3 + 1]; BT[it] = pfs[it * 3 + 2]; }
+                    if (k + 1 < N) fetch_stage(k + 1, rT);
+                }
                 T *ivk = tIV + k * IV_ROWS;
                 const T ul = o.ul, pc = o.pc;
                 if (TRAJ) {                    // xhat_k for the output sweep
