@@ -575,22 +575,31 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     BT[it] = real ? bb : T(0);
                 }
             };
-            if (SHARED) load_tiles_T(); else fetch_stage(0, rT);
+            if (SHARED) load_tiles_T();
             T xt[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
             // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
             int xslot[4];
             NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
             const int cslot = tc == 0 ? 12 + ta : 0, pslot = tc == 0 ? 16 + ta : 0;
-            struct Ops { T mt[4], z, ul, pc; };
-            // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon)
+            struct Ops { T mt[4], z, ul, pc, ab[SHARED ? 1 : 12]; };
+            const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // factors of stages [0, kl) come from LDS, [kl, N) from HBM
+            // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon).  Per-stage
+            // linearisation: the stage tiles (transposed) travel with them - two to four stages ahead, where one stage
+            // ahead left the 0.33 us stage waiting on a 1 us load - and the loop below covers the LDS-cached stages too
             auto fetch_ops = [&](int kq, Ops &o) {
                 const int k = kq < N ? kq : N - 1;
                 const T *lmn = tLM + k * TLM_ROWS;
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
-                o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+                if (SHARED || k >= kl) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
+                    o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+                }
                 o.ul = ulin(k, ta);
                 o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
+                if (!SHARED) {
+                    const T *a = tAB + (size_t)k * TAB_ROWS + rT;
+                    NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
+                }
             };
             // ... and from the LDS stage cache (scalars still come from global memory, one stage ahead)
             auto fetch_ops_lds = [&](int k, Ops &o) {
@@ -598,10 +607,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[jt * 16 + r];
                 o.z = lmn[64 + r];
             };
-            auto stageB = [&](int k, const Ops &o) {
+            auto stageB = [&](int k, Ops &o) {
                 if (!SHARED) {
-                    NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = pfs[it * 3]; AT3[it] = pfs[it * 3 + 1]; BT[it] = pfs[it * 3 + 2]; }
-                    if (k + 1 < N) fetch_stage(k + 1, rT);
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = o.ab[it * 3]; AT3[it] = o.ab[it * 3 + 1]; BT[it] = o.ab[it * 3 + 2]; }
+                    if (LDSC) { if (k < kl) fetch_ops_lds(k, o); }
                 }
                 T *ivk = tIV + k * IV_ROWS;
                 const T ul = o.ul, pc = o.pc;
@@ -654,9 +663,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
             };
             Ops oa[2], ob[2];
-            const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // stages [0, kl) come from LDS, [kl, N) from HBM
-            fetch_ops(kl, oa[0]); fetch_ops(kl + 1, oa[1]);     // the first HBM stages are in flight during the LDS phase
-            if constexpr (LDSC) {
+            const int kb = SHARED ? kl : 0;                      // first stage of the main loop
+            fetch_ops(kb, oa[0]); fetch_ops(kb + 1, oa[1]);     // (shared: the first HBM stages are in flight during the LDS phase)
+            if constexpr (LDSC && SHARED) {
                 if (kl > 0) {
                     Ops ol;
                     T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
@@ -671,7 +680,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     }
                 }
             }
-            for (int k0 = kl; k0 < N; k0 += 4) {
+            for (int k0 = kb; k0 < N; k0 += 4) {
                 fetch_ops(k0 + 2, ob[0]); fetch_ops(k0 + 3, ob[1]);
                 stageB(k0, oa[0]);
                 if (k0 + 1 < N) stageB(k0 + 1, oa[1]);
