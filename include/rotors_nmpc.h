@@ -213,6 +213,12 @@ int nmpc_hold_command_device(nmpc_solver *s, int B, const void *u0, const int32_
 int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next,
                            int normalize_q, void *hip_stream);
 
+/* one closed-loop tick's plant side in a single launch: nmpc_hold_command_device followed by nmpc_plant_step_device
+ * of the held command, the next measured state written over x [B][13] (nodes/mpc_controller_node:122-131,152-164 and
+ * the plant of SURVEY 8f-2).  Same results as the two calls; exists because a tick of 4096 vehicles is launch-bound */
+int nmpc_hold_and_step_device(nmpc_solver *s, int B, const void *u0, const int32_t *status, void *held, void *x,
+                              int normalize_q, void *hip_stream);
+
 /* adjoint sensitivities of the model (the CasADi-generated `expl_vde_adj` of controller.py:267-355, which
  * acados compiles next to expl_vde_forw).  x [B][13], u [B][4], lam [B][13] -> out [B][17]:
  *   continuous != 0:  ( f_x(x,u)' lam | f_u(x,u)' lam )          -- what expl_vde_adj evaluates

@@ -72,7 +72,7 @@ EXPORTS = (
     "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_stats", "nmpc_set_timing",
     "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
-    "nmpc_hold_command_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device",
+    "nmpc_hold_command_device", "nmpc_hold_and_step_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device",
 )
 
 
@@ -165,6 +165,8 @@ def load() -> C.CDLL:
     lib.nmpc_plant_step_device.restype = C.c_int
     lib.nmpc_hold_command_device.argtypes = [vp, C.c_int, vp, vp, vp, vp]
     lib.nmpc_hold_command_device.restype = C.c_int
+    lib.nmpc_hold_and_step_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+    lib.nmpc_hold_and_step_device.restype = C.c_int
     lib.nmpc_adjoint_sensitivities_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
     lib.nmpc_adjoint_sensitivities_device.restype = C.c_int
     lib.nmpc_kkt_report_device.argtypes = [vp, C.c_int, vp, vp, vp, vp, C.c_int, vp, vp]

@@ -128,6 +128,35 @@ __global__ void k_plant_step(Consts<T> c, int B, const T *__restrict__ x, const 
     NMPC_UNROLL for (int i = 0; i < NX; i++) xn[(size_t)b * NX + i] = xs[i];
 }
 
+// One closed-loop tick's plant side in ONE launch (rollout.py): hold the command (k_hold_command), fly it for one
+// shooting interval (k_plant_step) and leave the next measured state in place of the old one.
+template <class T>
+__global__ void k_hold_and_step(Consts<T> c, int B, const T *__restrict__ u0, const int32_t *__restrict__ status,
+                                Bounds4<T> bd, T *__restrict__ held, T *__restrict__ x, int normalize_q)
+{
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    T xs[NX], us[NU], f1[NX], xm[NX], f2[NX];
+    NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] = x[(size_t)b * NX + i];
+    const bool fresh = status[b] == 0;
+    NMPC_UNROLL for (int j = 0; j < NU; j++) {
+        const T h = held[(size_t)b * NU + j], v = fmin(fmax(u0[(size_t)b * NU + j], bd.lb[j]), bd.ub[j]);
+        us[j] = fresh ? v : h;
+        if (fresh) held[(size_t)b * NU + j] = v;
+    }
+    for (int st = 0; st < c.steps; st++) {
+        model_f(c, xs, us, f1);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + T(0.5) * c.h * f1[i];
+        model_f(c, xm, us, f2);
+        NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += c.h * f2[i];
+    }
+    if (normalize_q) {
+        const T n = sqrt(xs[6] * xs[6] + xs[7] * xs[7] + xs[8] * xs[8] + xs[9] * xs[9]);
+        if (n != T(0)) { NMPC_UNROLL for (int i = 6; i < 10; i++) xs[i] /= n; }
+    }
+    NMPC_UNROLL for (int i = 0; i < NX; i++) x[(size_t)b * NX + i] = xs[i];
+}
+
 // Adjoint sensitivities: model_adj / erk_adjoint live in nmpc_lane.hpp (host + device, so that the CPU build of the
 // kernel bodies tests them too); the two kernels below batch them.
 // out [B][17] = ( A' lam (13) | B' lam (4) ) of the interval that starts at (x, u); cont != 0: the continuous

@@ -911,6 +911,33 @@ int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, 
     return 0;
 }
 
+int nmpc_hold_and_step_device(nmpc_solver *s, int B, const void *u0, const int32_t *status, void *held, void *x,
+                              int normalize_q, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || !u0 || !status || !held || !x) return s->fail(NMPC_EARG, "hold_and_step: bad arguments");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const dim3 grid((B + 63) / 64), block(64);
+    if (s->cfg.dtype == NMPC_DTYPE_F64) {
+        Consts<double> c;
+        fill_consts(s->cfg, c);
+        Bounds4<double> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = s->cfg.lbu[i]; bd.ub[i] = s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_hold_and_step<double>, grid, block, 0, st, c, B, (const double *)u0, status, bd, (double *)held,
+                           (double *)x, normalize_q);
+    } else {
+        Consts<float> c;
+        fill_consts(s->cfg, c);
+        Bounds4<float> bd;
+        for (int i = 0; i < 4; i++) { bd.lb[i] = (float)s->cfg.lbu[i]; bd.ub[i] = (float)s->cfg.ubu[i]; }
+        hipLaunchKernelGGL(k_hold_and_step<float>, grid, block, 0, st, c, B, (const float *)u0, status, bd, (float *)held,
+                           (float *)x, normalize_q);
+    }
+    HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
 const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : nullptr; }
 const int32_t *nmpc_device_passes(nmpc_solver *s) { return s ? s->d_npol : nullptr; }
 

@@ -23,7 +23,7 @@ class ClosedLoopRollout:
         dev = torch.device("cuda", cfg.device)
         z = lambda *shape: torch.zeros(*shape, dtype=self.dt_t, device=dev)  # noqa: E731
         B, N = self.B, self.N
-        self.x, self.xn = z(B, 13), z(B, 13)
+        self.x = z(B, 13)
         self.u0, self.status = z(B, 4), torch.zeros(B, dtype=torch.int32, device=dev)
         self.xt = [z(B, N + 1, 13), z(B, N + 1, 13)]      # ping-pong warm-start trajectories
         self.ut = [z(B, N, 4), z(B, N, 4)]
@@ -44,9 +44,9 @@ class ClosedLoopRollout:
         # a failed solve returns zeros (controller.py:448-450) and the node keeps flying its last command
         # (nodes/mpc_controller_node:124-129); the solver has handed back the cold-start point for such an
         # instance, so its next tick restarts cold although the launch is a warm-started one
-        s.hold_command_device(B, self.u0.data_ptr(), self.status.data_ptr(), self.held.data_ptr(), stream)
-        s.plant_step_device(B, self.x.data_ptr(), self.held.data_ptr(), self.xn.data_ptr(), True, stream)
-        self.x.copy_(self.xn)                   # fixed buffers: the tick can be replayed from a HIP graph
+        # (one launch; the state is advanced in place - fixed buffers, so the tick can be replayed from a HIP graph)
+        s.hold_and_step_device(B, self.u0.data_ptr(), self.status.data_ptr(), self.held.data_ptr(), self.x.data_ptr(),
+                               True, stream)
 
     def run(self, x0: np.ndarray, steps: int, setpoint=(0.0, 0.0, 1.0), yaw: float = 0.0, log: bool = True,
             use_graph: bool = False):

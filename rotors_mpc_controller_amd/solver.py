@@ -143,6 +143,12 @@ class NmpcOcpSolver:
         """nodes/mpc_controller_node:122-131 batched: held [B,4] <- clip(u0) where status == 0, else unchanged."""
         self._check(self._lib.nmpc_hold_command_device(self._h, int(B), u0_ptr, status_ptr, held_ptr, stream or None))
 
+    def hold_and_step_device(self, B: int, u0_ptr: int, status_ptr: int, held_ptr: int, x_ptr: int,
+                             normalize_q: bool = True, stream: int = 0) -> None:
+        """hold_command_device + plant_step_device of the held command in one launch; x [B][13] is updated in place."""
+        self._check(self._lib.nmpc_hold_and_step_device(self._h, int(B), u0_ptr, status_ptr, held_ptr, x_ptr,
+                                                        int(normalize_q), stream or None))
+
     def plant_step_device(self, B: int, x_ptr: int, u_ptr: int, x_next_ptr: int, normalize_q: bool = True,
                           stream: int = 0) -> None:
         """One interval of the controller's own model/ERK as the plant of a closed-loop rollout."""

@@ -178,6 +178,29 @@ def test_hold_command_kernel_mirrors_the_node():
     np.testing.assert_array_equal(d_h.cpu().numpy(), want)
 
 
+def test_hold_and_step_equals_hold_then_plant_step():
+    """The one-launch tick of the closed loop (rollout.py) against the two kernels it fuses: bit-equal held commands and
+    next states, including vehicles whose solve failed (they fly the remembered command)."""
+    import torch
+    s = make_solver(max_batch=128)
+    B = 100
+    rng = np.random.default_rng(3)
+    x = sample_x0(B, 3, **AGGRESSIVE)
+    u0 = rng.uniform(-1.0, 8.0, (B, 4))
+    held = rng.uniform(0.5, 5.0, (B, 4))
+    status = (rng.uniform(size=B) < 0.3).astype(np.int32) * rng.integers(1, 5, B).astype(np.int32)
+    d_u, d_s = torch.from_numpy(u0).cuda(), torch.from_numpy(status).cuda()
+    h1, x1, xn = torch.from_numpy(held).cuda(), torch.from_numpy(x).cuda(), torch.zeros(B, 13, dtype=torch.float64).cuda()
+    s.hold_command_device(B, d_u.data_ptr(), d_s.data_ptr(), h1.data_ptr())
+    s.plant_step_device(B, x1.data_ptr(), h1.data_ptr(), xn.data_ptr(), True)
+    h2, x2 = torch.from_numpy(held).cuda(), torch.from_numpy(x).cuda()
+    s.hold_and_step_device(B, d_u.data_ptr(), d_s.data_ptr(), h2.data_ptr(), x2.data_ptr(), True)
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(h2.cpu().numpy(), h1.cpu().numpy())
+    np.testing.assert_array_equal(x2.cpu().numpy(), xn.cpu().numpy())
+    assert (status != 0).any() and not np.array_equal(xn.cpu().numpy(), x)
+
+
 def test_solver_first_then_torch_share_one_hip_runtime():
     """A consumer that creates and runs the solver BEFORE torch is imported, then uses torch.cuda, then the
     solver again: one HIP runtime serves both (no import-order dependence, VERDICT r1 weak #8)."""
