@@ -584,12 +584,13 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             const int cslot = tc == 0 ? 12 + ta : 0, pslot = tc == 0 ? 16 + ta : 0;
             struct Ops { T mt[4], z, ul, pc, ab[SHARED ? 1 : 12]; };
             const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // factors of stages [0, kl) come from LDS, [kl, N) from HBM
-            // operands of stage kq from the HBM scratch (prefetches that run past the horizon are skipped).  Per-stage
+            // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon).  Per-stage
             // linearisation: the stage tiles (transposed) travel with them - two to four stages ahead, where one stage
             // ahead left the 0.33 us stage waiting on a 1 us load - and the loop below covers the LDS-cached stages too
             auto fetch_ops = [&](int kq, Ops &o) {
-                if (kq >= N) return;                 // (wave-uniform)
-                const int k = kq;
+                const int k = kq < N ? kq : N - 1;   // clamped, NOT skipped: a branch around the loads makes the compiler's
+                                                     // wait-count model assume the fewest loads in flight, and every stage
+                                                     // then waits for the prefetch issued just before it
                 const T *lmn = tLM + k * TLM_ROWS;
                 if (SHARED || k >= kl) {
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
