@@ -378,9 +378,12 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const bool traj = out.x_out != nullptr || out.u_out != nullptr;
     const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
     int occ_as = s->team_occ;
-    // two waves per SIMD need >= 2048 waves; the per-stage variant spills inside its sweeps at 256 registers
-    // (measured slower than one wave per SIMD at every batch size), so only the shared variant takes it
-    if (occ_as == 0) occ_as = ((B + tpw - 1) / tpw >= 2048) ? 2 : 1;
+    // Two waves per SIMD (256 registers, no LDS stage cache) pay only where one wave per SIMD would leave a second,
+    // part-filled round: between 1024 and 2048 waves (B = 6144: 50.6 against 48.3 M solves/s, B = 8192: 63.8 / 62.7).
+    // From 3072 waves up the one-wave build with its stage cache wins (B = 12288: 74.0 / 69.2, B = 65536: 93.8 / 91.4).
+    // The per-stage variant spills inside its sweeps at 256 registers and never takes the two-wave build.
+    const int nwaves = (B + tpw - 1) / tpw;
+    if (occ_as == 0) occ_as = (nwaves > 1024 && nwaves <= 2048) ? 2 : 1;
     if (!c.shared) occ_as = 1;
     // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD) holds the
     // factors of the first stages; the team stride stays 192 B past a multiple of the 256-B bank row (24 doubles mod 32).
