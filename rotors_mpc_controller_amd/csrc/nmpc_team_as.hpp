@@ -142,6 +142,15 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         Qdg[t] = (ta == tc && natR[t] >= 0) ? qd : T(0);
     }
     const int polish_passes = c.polish_passes;
+    // where lane (a,c) finds its entries of column / row 15 of the stage cost in the gradient buffer sh: a natural row,
+    // or the slot that holds 0.0 (one LDS read and no select per entry in every factor stage)
+    constexpr int ZSLOT = A_RED + 32 - A_H;
+    int iq_col[4], iq_row[4];
+    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+        iq_col[t] = (tc == 3 && natR[t] >= 0) ? natR[t] : ZSLOT;
+        iq_row[t] = (ta == 3 && natC[t] >= 0) ? natC[t] : ZSLOT;
+    }
+    if (r == 0) sRed[32] = T(0);
     const T Idt = (ta == tc) ? T(1) : T(0);
     const T HuuD = (ta == tc) ? Rd_a : T(0);          // diagonal of Huu without pins
     NMPC_STAMP(2)
@@ -452,12 +461,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 // the (q,w) x (q,w) tiles of Abar'(Pbar Abar) and the (p,v) rows: independent of the Cholesky
                 T Pn[4][4];
                 if (!LAST) {
-                    T qcol[4], qrow[4];
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) {
-                        const T qa = sh[natR[t] >= 0 ? natR[t] : 0], qb = sh[natC[t] >= 0 ? natC[t] : 0];
-                        qcol[t] = (tc == 3 && natR[t] >= 0) ? qa : T(0);
-                        qrow[t] = (ta == 3 && natC[t] >= 0) ? qb : T(0);
-                    }
+                    T qcol[4], qrow[4];       // column / row 15 of Qbar: the stage gradient, zero elsewhere (read from a zero slot)
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
                     // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                         T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
