@@ -214,6 +214,62 @@ def test_argument_errors_raise():
         s.set(3, "lbx", np.zeros(13))
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_randomised_vehicle_tuning_and_references(seed):
+    """What PositionNMPC.reconfigure can change (controller.py:63-172: mass, inertia, arm length, rotor constants ->
+    thrust bounds and hover thrust; the weights; the horizon, dt and the integrator's step count), drawn at random, with
+    per-instance moving references and tighter thrust boxes so that bounds are active: the GPU path (active-set kernel
+    for 1-2 integrator steps, the general kernel for 3; both linearisation variants) against the oracle built from the
+    same numbers."""
+    from tests.oracle_solver import OracleOcpSolver
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.choice([3, 9, 20, 31]))
+    mass = float(rng.uniform(0.4, 3.0))
+    arm = float(rng.uniform(0.1, 0.4))
+    km = float(rng.uniform(0.005, 0.03))
+    hov = mass * 9.81 / 4.0
+    over = dict(N=N, dt=float(rng.choice([0.02, 0.05, 0.08])), mass=mass,
+                inertia=[float(v) for v in rng.uniform(0.003, 0.03, 3) * mass],
+                rotor_x=[arm, 0.0, -arm, 0.0], rotor_y=[0.0, arm, 0.0, -arm], rotor_z=[-km, km, -km, km],
+                lbu=[float(hov * rng.uniform(0.0, 0.3))] * 4, ubu=[float(hov * rng.uniform(1.6, 3.5))] * 4,
+                W=[float(v) for v in 10.0 ** rng.uniform(-2, 1.5, 17)], W_e=[float(v) for v in 10.0 ** rng.uniform(-1, 2, 13)],
+                levenberg_marquardt=float(rng.choice([0.0, 7e-3, 0.1])), sim_num_steps=int(rng.choice([1, 2, 3])),
+                lm_scaled_by_dt=int(rng.integers(0, 2)), cost_scaled_by_dt=int(rng.integers(0, 2)),
+                flags=_lib.FLAG_TEAM_MAPPING | int(rng.integers(0, 2)), max_batch=128)
+    s = make_solver(**over)
+    c = OracleOcpSolver(s.config).c
+    c.qp_polish = 1
+    B = 96
+    x0 = sample_x0(B, 2000 + seed, **AGGRESSIVE)
+    # per-instance references: a setpoint that moves along the horizon, hover thrust of THIS vehicle
+    yref = np.zeros((B, N, 17)); ye = np.zeros((B, 13))
+    goal = rng.normal(0.0, 1.0, (B, 3)) + np.array([0.0, 0.0, 1.0])
+    vel = rng.normal(0.0, 0.3, (B, 3))
+    for k in range(N + 1):
+        row = np.zeros((B, 13)); row[:, 0:3] = goal + vel * (k * over["dt"]); row[:, 3:6] = vel; row[:, 6] = 1.0
+        if k < N:
+            yref[:, k, :13] = row; yref[:, k, 13:] = hov
+        else:
+            ye[:] = row
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    ref = O.solve_batch(c, x0, yref, ye, want_traj=True, nthreads=8)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    ok = ref["status"] == 0
+    assert ok.sum() >= B - 4
+    scale = max(1.0, hov)
+    np.testing.assert_allclose(out["u0"][ok], ref["u0"][ok], rtol=0, atol=TOL_U * scale)
+    np.testing.assert_allclose(out["x"][ok], ref["x"][ok], rtol=0, atol=TOL_X * scale)
+    np.testing.assert_allclose(out["u"][ok], ref["u"][ok], rtol=0, atol=TOL_X * scale)
+    at_bound = (np.abs(out["u"][ok] - over["lbu"][0]) < 1e-9) | (np.abs(out["u"][ok] - over["ubu"][0]) < 1e-9)
+    assert at_bound.any() or seed not in (0,)          # the draw exercises active bounds (checked on the first seed)
+    # second tick, warm-started from the first (per-stage linearisation whatever the flag says)
+    out2 = s.solve_batch(x0, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
+    ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=8)
+    np.testing.assert_array_equal(out2["status"], ref2["status"])
+    ok2 = ok & (ref2["status"] == 0)
+    np.testing.assert_allclose(out2["u0"][ok2], ref2["u0"][ok2], rtol=0, atol=10 * TOL_U * scale)
+
+
 @pytest.mark.parametrize("N,cond_N", [(20, 5), (20, 3), (7, 5)])
 def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
     """SURVEY 8a7 on the GPU: k_cond_ipm (condense -> IPM on dense blocks -> expand) vs the oracle's
