@@ -669,8 +669,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 kchgB = (npc != pc) ? k : kchgB;                               // ascending k: the last one is the highest
                 NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
             };
-            // Stages in flight: two sets of H = 2.  (A stage from LDS takes 0.2 us, one whose operands come from HBM 0.5 us;
-            // 2 x 3 and 2 x 4 stages in flight, also issued ahead of the LDS phase, measured the same 61-62 M solves/s.)
+            // Stages in flight: two sets of H = 2.  (The stage sits on its dependent MFMA chain - 0.3 us whether the operands
+            // come from LDS or from HBM; 2 x 3 and 2 x 4 stages in flight, also issued ahead of the LDS phase, measured the
+            // same 61-63 M solves/s.)
             constexpr int H = 2;
             constexpr bool PRE = false;
             Ops oa[H], ob[H];

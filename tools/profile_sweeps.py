@@ -15,7 +15,7 @@ import numpy as np
 
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
-os.environ["ROTORS_NMPC_LIB"] = str(ROOT / "rotors_mpc_controller_amd" / "librotors_nmpc_hip_prof.so")
+os.environ["ROTORS_NMPC_LIB"] = os.environ.get("NMPC_PROF_LIB", str(ROOT / "rotors_mpc_controller_amd" / "librotors_nmpc_hip_prof.so"))
 
 import torch  # noqa: E402
 
@@ -30,6 +30,7 @@ ap.add_argument("--no-share", action="store_true")
 ap.add_argument("--mapping", default="team")
 ap.add_argument("--dist", default="near_hover")
 ap.add_argument("--no-polish", action="store_true")
+ap.add_argument("--polish-passes", type=int, default=0)
 a = ap.parse_args()
 
 B = a.batch
@@ -37,6 +38,8 @@ cfg = _lib.default_config(max_batch=B, dtype=_lib.DTYPE_F64 if a.dtype == "f64" 
                           flags=(0 if a.no_share else 1) | (2 if a.mapping == 'team' else 0))
 if a.no_polish:
     cfg.update(qp_polish=0)
+if a.polish_passes:
+    cfg.update(qp_polish_passes=a.polish_passes, qp_polish_budget=a.polish_passes)
 if a.dtype == "f32":
     cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
 s = NmpcOcpSolver(cfg)
