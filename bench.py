@@ -147,30 +147,24 @@ def secondary_rows(args, B, N, local, dev, tdt, npdt, torch, _lib, NmpcOcpSolver
     # independent batches (Monte-Carlo use): two solver handles on two streams, batches alternate between them.  The
     # tail of one batch - the few waves whose instances need more active-set passes - runs beside the start of the next
     if args.dtype in ("f64", "f32io"):
-        pair = []
-        for i in range(2):
-            cfg = _lib.default_config(N=N, max_batch=B, device=local,
-                                      dtype=dict(f64=_lib.DTYPE_F64, f32io=_lib.DTYPE_F32IO)[args.dtype])
-            sv = NmpcOcpSolver(cfg)
-            sv.set_timing(False)
-            pair.append((sv, torch.cuda.Stream(dev), torch.zeros(B, 4, dtype=tdt, device=dev),
-                         torch.zeros(B, dtype=torch.int32, device=dev)))
-        for _, st_i, _, _ in pair:
-            st_i.wait_stream(stream)
+        from rotors_mpc_controller_amd.pipeline import BatchPipeline
+        pipe = BatchPipeline(_lib.default_config(N=N, max_batch=B, device=local,
+                                                 dtype=dict(f64=_lib.DTYPE_F64, f32io=_lib.DTYPE_F32IO)[args.dtype]), depth=2)
+        outs = [(torch.zeros(B, 4, dtype=tdt, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(2)]
         tick = [0]
 
         def launch2():
-            sv, st_i, u_i, s_i = pair[tick[0] & 1]
+            u_i, s_i = outs[tick[0] & 1]
             tick[0] += 1
-            sv.solve_batch_device(B, x0_near.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u_i.data_ptr(),
-                                  status_ptr=s_i.data_ptr(), stream=st_i.cuda_stream)
+            pipe.submit(B, x0_near.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u_i.data_ptr(), status_ptr=s_i.data_ptr(),
+                        after_current_stream=False)          # inputs are resident long before
         rate, ms = timed_rate(None, B, launch2, 2 * max(10, args.steps // 4), 6, torch, dev)
-        same = bool(torch.equal(pair[0][2], pair[1][2]) and int(pair[0][3].abs().sum()) == 0)
+        same = bool(torch.equal(outs[0][0], outs[1][0]) and int(outs[0][1].abs().sum()) == 0)
         rows["two_batches_in_flight"] = dict(value=rate, unit="solves/s", ms_per_step=ms, outputs_equal=same,
                                              what="independent batches alternate between two solver handles on two streams "
-                                                  "(the headline value is one handle, one stream, launches back to back)")
-        for sv, _, _, _ in pair:
-            sv.close()
+                                                  "(rotors_mpc_controller_amd.pipeline.BatchPipeline; the headline value is one "
+                                                  "handle, one stream, launches back to back)")
+        pipe.close()
     return rows
 
 

@@ -225,6 +225,32 @@ def test_two_waves_per_simd_build_equals_the_one_wave_build():
     np.testing.assert_allclose(big["u0"][idx], ref["u0"], rtol=0, atol=1e-9)
 
 
+def test_batch_pipeline_equals_one_handle():
+    """BatchPipeline (independent batches on `depth` handles / streams): six different batches in flight three at a
+    time give, bit for bit, what one handle gives for each of them."""
+    import torch
+    from rotors_mpc_controller_amd.pipeline import BatchPipeline
+    B = 1024
+    cfg = _lib.default_config(max_batch=B)
+    yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
+    d_y, d_ye = torch.from_numpy(yref).cuda(), torch.from_numpy(ye).cuda()
+    x0s = [sample_x0(B, 40 + i, **(AGGRESSIVE if i % 2 else NEAR_HOVER)) for i in range(6)]
+    d_x = [torch.from_numpy(x).cuda() for x in x0s]
+    d_u = [torch.zeros(B, 4, dtype=torch.float64, device="cuda") for _ in range(6)]
+    d_s = [torch.full((B,), -1, dtype=torch.int32, device="cuda") for _ in range(6)]
+    pipe = BatchPipeline(cfg, depth=3)
+    slots = [pipe.submit(B, d_x[i].data_ptr(), d_y.data_ptr(), d_ye.data_ptr(), True, d_u[i].data_ptr(),
+                         status_ptr=d_s[i].data_ptr()) for i in range(6)]
+    assert slots == [0, 1, 2, 0, 1, 2]
+    pipe.synchronize()
+    s = make_solver(max_batch=B)
+    for i in range(6):
+        ref = s.solve_batch(x0s[i], yref, ye)
+        np.testing.assert_array_equal(d_s[i].cpu().numpy(), ref["status"])
+        np.testing.assert_array_equal(d_u[i].cpu().numpy(), ref["u0"])
+    pipe.close()
+
+
 def test_solver_first_then_torch_share_one_hip_runtime():
     """A consumer that creates and runs the solver BEFORE torch is imported, then uses torch.cuda, then the
     solver again: one HIP runtime serves both (no import-order dependence, VERDICT r1 weak #8)."""
