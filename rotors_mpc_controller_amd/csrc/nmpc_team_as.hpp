@@ -35,7 +35,7 @@
 namespace nmpc {
 
 constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
-constexpr int AS_EV = 48;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2 | [32..44] b_k
+constexpr int AS_EV = 64;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2 | [32..44] b_k | [48..63] R e3 / m at the 4 points
 constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 // LDS carve per team, in doubles
@@ -48,14 +48,16 @@ constexpr int A_H = A_D + 16;        // [16]     stage gradient, natural rows
 constexpr int A_XH = A_H + 16;       // [16]
 constexpr int A_RED = A_XH + 16;     // [32]     small reductions
 constexpr int A_EV = A_RED + 40;     // evaluation points of the linearisation
-// team strides 2752 B / 4544 B = 192 B past a multiple of the 256-B bank row (see TEAM_LDS in nmpc_team.hpp)
-constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 360
-constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 696
+// (the host pads the team stride - carve + stage cache - to 192 B past a multiple of the 256-B bank row: see TEAM_LDS in nmpc_team.hpp)
+constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 376
+constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 824
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
-// transposed Jacobian tiles at an evaluation point given as (q, omega, t2 = 2 (sum u) / m)
-__device__ __forceinline__ void jac_tiles_ev(double inv_mass, const JacCoef<double> &k, const double *e, double t2, int ta,
+// transposed Jacobian tiles at an evaluation point given as (q, omega, t2 = 2 (sum u) / m); re3 = (R e3 / m, 0): the thrust
+// direction column, quadratic in q, comes from the lane that integrated the stage (thrust_dir below) - one LDS read here
+// instead of ten FP64 operations and three selects per point in every lane
+__device__ __forceinline__ void jac_tiles_ev(const JacCoef<double> &k, const double *e, const double *re3, double t2, int ta,
                                              double &FvqT, double &FqqT, double &FqwT, double &FwwT, double &r3a)
 {
     const double qw = e[0], qx = e[1], qy = e[2], qz = e[3], wx = e[4], wy = e[5], wz = e[6];
@@ -63,9 +65,15 @@ __device__ __forceinline__ void jac_tiles_ev(double inv_mass, const JacCoef<doub
     FqqT = k.qq[0] * wx + k.qq[1] * wy + k.qq[2] * wz;
     FqwT = k.qw[0] * qw + k.qw[1] * qx + k.qw[2] * qy + k.qw[3] * qz;
     FwwT = k.ww[0] * wx + k.ww[1] * wy + k.ww[2] * wz;
-    const double r0 = 2.0 * (qx * qz + qw * qy) * inv_mass, r1 = 2.0 * (qy * qz - qw * qx) * inv_mass,
-                 r2 = (1.0 - 2.0 * (qx * qx + qy * qy)) * inv_mass;
-    r3a = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : 0.0));
+    r3a = re3[ta];
+}
+__device__ __forceinline__ void thrust_dir(double inv_mass, const double *x, double *out)
+{
+    const double qw = x[6], qx = x[7], qy = x[8], qz = x[9];
+    out[0] = 2.0 * (qx * qz + qw * qy) * inv_mass;
+    out[1] = 2.0 * (qy * qz - qw * qx) * inv_mass;
+    out[2] = (1.0 - 2.0 * (qx * qx + qy * qy)) * inv_mass;
+    out[3] = 0.0;
 }
 
 // work list of the instances the active-set kernel hands to the general kernel
@@ -180,6 +188,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + hh * f1[i];
                     if (mine) {
                         NMPC_UNROLL for (int i = 0; i < 7; i++) { ev[st * 14 + i] = xs[6 + i]; ev[st * 14 + 7 + i] = xm[6 + i]; }
+                        thrust_dir(inv_mass, xs, ev + 48 + st * 8);
+                        thrust_dir(inv_mass, xm, ev + 48 + st * 8 + 4);
                     }
                     model_f(c, xm, us, f2);
                     NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += hstep * f2[i];
@@ -216,7 +226,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     T K[PB][4][3], Sm[PB][4][3];
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
-                        jac_tiles_ev(inv_mass, jk, ev[q] + st * 14, t2[q], ta, a1, a2, a3, a4, a5);
+                        jac_tiles_ev(jk, ev[q] + st * 14, ev[q] + 48 + st * 8, t2[q], ta, a1, a2, a3, a4, a5);
                         vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
@@ -226,7 +236,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
-                        jac_tiles_ev(inv_mass, jk, ev[q] + st * 14 + 7, t2[q], ta, a1, a2, a3, a4, a5);
+                        jac_tiles_ev(jk, ev[q] + st * 14 + 7, ev[q] + 48 + st * 8 + 4, t2[q], ta, a1, a2, a3, a4, a5);
                         vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
@@ -482,43 +492,51 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
                     }
                 }
-                // Cholesky (replicated in every lane of the team)
-                NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
-                    T d = Lf[lidx(jj, jj)];
-                    NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
-                    const bool pos = d > T(0);
-                    ok &= pos; nanp |= !(d == d); d = pos ? d : T(1);
-                    const T rd = fast_rsqrt(d);
-                    Lf[lidx(jj, jj)] = rd;
-                    NMPC_UNROLL for (int i = jj + 1; i < NU; i++) {
-                        T a = Lf[lidx(i, jj)];
-                        NMPC_UNROLL for (int l = 0; l < jj; l++) a -= Lf[lidx(i, l)] * Lf[lidx(jj, l)];
-                        Lf[lidx(i, jj)] = a * rd;
-                    }
+                // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
+                // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
+                // triangle needs 4 FMAs where the general one needed 16 operations, and FP64 vector instructions are paid
+                // in full here - they share the SIMD's double-precision pipe with the MFMAs.
+                // c_ij = l_ij d_j are the unscaled column entries.
+                T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
+                {
+                    const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
+                    const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
+                    auto pivot = [&](T d) -> T {
+                        const bool pos = d > T(0);
+                        ok &= pos; nanp |= !(d == d);
+                        return fast_rcp(pos ? d : T(1));
+                    };
+                    r0 = pivot(h00);
+                    l10 = h10 * r0; l20 = h20 * r0; l30 = h30 * r0;
+                    r1 = pivot(h11 - l10 * h10);
+                    const T c21 = h21 - l20 * h10, c31 = h31 - l30 * h10;
+                    l21 = c21 * r1; l31 = c31 * r1;
+                    r2 = pivot(h22 - l20 * h20 - l21 * c21);
+                    const T c32 = h32 - l30 * h20 - l31 * c21;
+                    l32 = c32 * r2;
+                    r3 = pivot(h33 - l30 * h30 - l31 * c31 - l32 * c32);
                 }
-                // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the 4x4 triangle in closed form (the
-                // diagonal of Lf already holds 1 / L_ii) and one select by the lane's (c,a): straight-line code - a
-                // forward substitution on the unit vector e_a, as the general kernel does it, compiles to lane-divergent
-                // branches that cut the stage's scheduling region
+                // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the unit triangle in closed form and
+                // one select by the lane's (c,a): straight-line code - a forward substitution on the unit vector e_a, as
+                // the general kernel does it, compiles to lane-divergent branches that cut the stage's scheduling region
                 T Y;
                 {
-                    const T i00 = Lf[lidx(0, 0)], i11 = Lf[lidx(1, 1)], i22 = Lf[lidx(2, 2)], i33 = Lf[lidx(3, 3)];
-                    const T l10 = Lf[lidx(1, 0)], l20 = Lf[lidx(2, 0)], l21 = Lf[lidx(2, 1)];
-                    const T l30 = Lf[lidx(3, 0)], l31 = Lf[lidx(3, 1)], l32 = Lf[lidx(3, 2)];
-                    const T i10 = -i11 * (l10 * i00);
-                    const T i21 = -i22 * (l21 * i11);
-                    const T i32 = -i33 * (l32 * i22);
-                    const T i20 = -i22 * (l20 * i00 + l21 * i10);
-                    const T i31 = -i33 * (l31 * i11 + l32 * i21);
-                    const T i30 = -i33 * (l30 * i00 + l31 * i10 + l32 * i20);
+                    const T i10 = -l10, i21 = -l21, i32 = -l32;
+                    const T i20 = -(l20 + l21 * i10);
+                    const T i31 = -(l31 + l32 * i21);
+                    const T i30 = -(l30 + l31 * i10 + l32 * i20);
                     const int e = tc * 4 + ta;           // (row c, column a) of L^-1
-                    Y = T(0);
-                    Y = e == 0 ? i00 : Y;  Y = e == 4 ? i10 : Y;  Y = e == 5 ? i11 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
-                    Y = e == 10 ? i22 : Y; Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y; Y = e == 15 ? i33 : Y;
+                    Y = (ta == tc) ? T(1) : T(0);
+                    Y = e == 4 ? i10 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
+                    Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y;
                 }
-                T M[4];
+                // M0 = L^-1 X, M = D^-1 M0 (row a of the tile by 1 / d_a): the feedback is u = -L^-T (M xbar), the Riccati
+                // update subtracts M0' M
+                const T ra = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : r3));
+                T M0[4], M[4];
                 NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                    M[jt] = mfma44(Y, X[jt], T(0));
+                    M0[jt] = mfma44(Y, X[jt], T(0));
+                    M[jt] = ra * M0[jt];
                     // stored where the forward sweep reads it transposed
                     if (LDSST) sLM[k * AS_LM_ROWS + jt * 16 + tc * 4 + ta] = M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
                 }
@@ -526,7 +544,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 if (LDSST) sLM[k * AS_LM_ROWS + 64 + r] = Zt; else lmk[TLM_Z + r] = Zt;
                 if (!LAST) {
                     T Mn[4];
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M[t];
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
                         NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
                     }
