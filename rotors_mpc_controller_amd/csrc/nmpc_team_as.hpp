@@ -480,7 +480,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                                 a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                                a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                                if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);     // tile (3,2) is the transpose of (2,3), below
                             }
                         }
                         Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
@@ -491,6 +491,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     NMPC_UNROLL for (int it = 2; it < 4; it++) {
                         NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
                     }
+                    Pn[3][2] = mfma44(Pn[2][3], Idt, T(0));    // (computing only the upper tiles and transposing the UPDATED ones - 95
+                                                               // MFMAs instead of 100 - measured no faster: the transposes then sit
+                                                               // at the end of the stage's dependency chain)
                 }
                 // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
                 // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
