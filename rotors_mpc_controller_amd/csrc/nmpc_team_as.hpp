@@ -35,7 +35,8 @@
 namespace nmpc {
 
 constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
-constexpr int AS_EV = 64;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 + t2 | [32..44] b_k | [48..63] R e3 / m at the 4 points
+constexpr int AS_EV = 56;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 | t2 | b_k | R e3 / m at the 4 points | 0
+constexpr int EV_T2 = 28, EV_B = 29, EV_RE = 42, EV_ZERO = 54;
 constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 // LDS carve per team, in doubles
@@ -49,15 +50,15 @@ constexpr int A_XH = A_H + 16;       // [16]
 constexpr int A_RED = A_XH + 16;     // [32]     small reductions
 constexpr int A_EV = A_RED + 40;     // evaluation points of the linearisation
 // (the host pads the team stride - carve + stage cache - to 192 B past a multiple of the 256-B bank row: see TEAM_LDS in nmpc_team.hpp)
-constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 376
-constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 824
+constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 368
+constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 760
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
 // transposed Jacobian tiles at an evaluation point given as (q, omega, t2 = 2 (sum u) / m); re3 = (R e3 / m, 0): the thrust
 // direction column, quadratic in q, comes from the lane that integrated the stage (thrust_dir below) - one LDS read here
 // instead of ten FP64 operations and three selects per point in every lane
-__device__ __forceinline__ void jac_tiles_ev(const JacCoef<double> &k, const double *e, const double *re3, double t2, int ta,
+__device__ __forceinline__ void jac_tiles_ev(const JacCoef<double> &k, const double *e, double re3a, double t2,
                                              double &FvqT, double &FqqT, double &FqwT, double &FwwT, double &r3a)
 {
     const double qw = e[0], qx = e[1], qy = e[2], qz = e[3], wx = e[4], wy = e[5], wz = e[6];
@@ -65,7 +66,7 @@ __device__ __forceinline__ void jac_tiles_ev(const JacCoef<double> &k, const dou
     FqqT = k.qq[0] * wx + k.qq[1] * wy + k.qq[2] * wz;
     FqwT = k.qw[0] * qw + k.qw[1] * qx + k.qw[2] * qy + k.qw[3] * qz;
     FwwT = k.ww[0] * wx + k.ww[1] * wy + k.ww[2] * wz;
-    r3a = re3[ta];
+    r3a = re3a;
 }
 __device__ __forceinline__ void thrust_dir(double inv_mass, const double *x, double *out)
 {
@@ -73,7 +74,6 @@ __device__ __forceinline__ void thrust_dir(double inv_mass, const double *x, dou
     out[0] = 2.0 * (qx * qz + qw * qy) * inv_mass;
     out[1] = 2.0 * (qy * qz - qw * qx) * inv_mass;
     out[2] = (1.0 - 2.0 * (qx * qx + qy * qy)) * inv_mass;
-    out[3] = 0.0;
 }
 
 // work list of the instances the active-set kernel hands to the general kernel
@@ -188,18 +188,18 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     NMPC_UNROLL for (int i = 0; i < NX; i++) xm[i] = xs[i] + hh * f1[i];
                     if (mine) {
                         NMPC_UNROLL for (int i = 0; i < 7; i++) { ev[st * 14 + i] = xs[6 + i]; ev[st * 14 + 7 + i] = xm[6 + i]; }
-                        thrust_dir(inv_mass, xs, ev + 48 + st * 8);
-                        thrust_dir(inv_mass, xm, ev + 48 + st * 8 + 4);
+                        thrust_dir(inv_mass, xs, ev + EV_RE + st * 6);
+                        thrust_dir(inv_mass, xm, ev + EV_RE + st * 6 + 3);
                     }
                     model_f(c, xm, us, f2);
                     NMPC_UNROLL for (int i = 0; i < NX; i++) xs[i] += hstep * f2[i];
                 }
                 if (mine) {
-                    ev[28] = T(2) * (us[0] + us[1] + us[2] + us[3]) * inv_mass;
+                    ev[EV_T2] = T(2) * (us[0] + us[1] + us[2] + us[3]) * inv_mass; ev[EV_ZERO] = T(0);
                     if (SHARED) {
                         NMPC_UNROLL for (int i = 0; i < NX; i++) sbv[i] = xs[i] - xn1[i];
                     } else {
-                        NMPC_UNROLL for (int i = 0; i < NX; i++) ev[32 + i] = xs[i] - xn1[i];
+                        NMPC_UNROLL for (int i = 0; i < NX; i++) ev[EV_B + i] = xs[i] - xn1[i];
                     }
                 }
             }
@@ -208,6 +208,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             // ---- phase B: forward sensitivities of the stages of the chunk, tile form, TWO stages at a time: their MFMA
             // chains are independent, so one stage's variational-equation products run in the latency of the other's
             constexpr int PB = SHARED ? 1 : 2;
+            const int ire = ta < 3 ? EV_RE + ta : EV_ZERO, sre = ta < 3 ? 3 : 0;     // lane's entry of R e3 / m at point p: ire + sre p (row 3: the zero slot)
             for (int e0 = 0; e0 < CH; e0 += PB) {
                 if (k0 + e0 >= Ns) break;
                 const T *ev[PB];
@@ -215,7 +216,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_UNROLL for (int q = 0; q < PB; q++) {
                     const int e = (e0 + q < CH && k0 + e0 + q < Ns) ? e0 + q : e0;      // an odd tail repeats the last stage
                     ev[q] = sEv + e * AS_EV;
-                    t2[q] = ev[q][28];
+                    t2[q] = ev[q][EV_T2];
                     NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
                         NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[q][rt][ct] = 0;
                     }
@@ -226,7 +227,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     T K[PB][4][3], Sm[PB][4][3];
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
-                        jac_tiles_ev(jk, ev[q] + st * 14, ev[q] + 48 + st * 8, t2[q], ta, a1, a2, a3, a4, a5);
+                        jac_tiles_ev(jk, ev[q] + st * 14, ev[q][ire + sre * (2 * st)], t2[q], a1, a2, a3, a4, a5);
                         vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
@@ -236,7 +237,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
-                        jac_tiles_ev(jk, ev[q] + st * 14 + 7, ev[q] + 48 + st * 8 + 4, t2[q], ta, a1, a2, a3, a4, a5);
+                        jac_tiles_ev(jk, ev[q] + st * 14 + 7, ev[q][ire + sre * (2 * st + 1)], t2[q], a1, a2, a3, a4, a5);
                         vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
@@ -264,7 +265,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                             // and the homogeneous 1 sit in column 15.)
                             T *a = tAB + (size_t)k * TAB_ROWS + r;
                             NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                                const T bq = ev[q][32 + (natR[rt] >= 0 ? natR[rt] : 0)];
+                                const T bq = ev[q][EV_B + (natR[rt] >= 0 ? natR[rt] : 0)];
                                 const T c15 = natR[rt] >= 0 ? bq : ((rt == 3 && ta == 3) ? T(1) : T(0));
                                 a[(rt * 3 + 0) * 16] = Sx[q][rt][0];
                                 a[(rt * 3 + 1) * 16] = tc < 3 ? Sx[q][rt][1] : c15;
