@@ -437,12 +437,14 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_WSYNC();
                 T Lf[10];
                 NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
-                // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt))
+                // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt)).  Tile (3,0) of Abar -
+                // d omega+ / d q and the homogeneous row - is identically zero (the body rates do not depend on the attitude):
+                // its products are left out here, in the (q,w) x (q,w) block below and in the forward sweep (94 MFMAs per stage)
                 T W0[4], W1[4];
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
                     T a0 = 0, a1 = 0;
                     NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                        a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                        if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
                         a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
                     }
                     W0[it] = a0; W1[it] = a1;
@@ -480,7 +482,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                                a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                                if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
                                 if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);     // tile (3,2) is the transpose of (2,3), below
                             }
                         }
@@ -649,7 +651,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 }
                 T xn[4];
                 xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
-                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);   // tile (3,0) of Abar is zero
                 const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
                           + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
                 const T ut = -mfma44(o.z, v, T(0));                           // lane (a,0): u_a
