@@ -1580,14 +1580,20 @@ __device__ __forceinline__ void jac_tiles(const Consts<T> &c, const JacCoef<T> &
 }
 
 // K = J S + [0 | f_u]: S, K are 4 row tiles (p_, v_, q, w_) x 3 column tiles (q | w_ | u)
-template <class T>
+// ZWQ: the caller keeps tile (3,0) - d omega / d q, identically zero - out of its updates: its products are skipped
+template <class T, bool ZWQ = false>
 __device__ __forceinline__ void vde_tiles(T FvqT, T FqqT, T FqwT, T FwwT, T r3a, T fu, const T S[4][3], T K[4][3])
 {
     NMPC_UNROLL for (int ct = 0; ct < 3; ct++) {
         K[0][ct] = S[1][ct];
         K[1][ct] = mfma44(FvqT, S[2][ct], ct == 2 ? r3a : T(0));
-        K[2][ct] = mfma44(FqwT, S[3][ct], mfma44(FqqT, S[2][ct], T(0)));
-        K[3][ct] = mfma44(FwwT, S[3][ct], ct == 2 ? fu : T(0));
+        if (ZWQ && ct == 0) {
+            K[2][ct] = mfma44(FqqT, S[2][ct], T(0));
+            K[3][ct] = T(0);
+        } else {
+            K[2][ct] = mfma44(FqwT, S[3][ct], mfma44(FqqT, S[2][ct], T(0)));
+            K[3][ct] = mfma44(FwwT, S[3][ct], ct == 2 ? fu : T(0));
+        }
     }
 }
 

@@ -228,21 +228,21 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
                         jac_tiles_ev(jk, ev[q] + st * 14, ev[q][ire + sre * (2 * st)], t2[q], a1, a2, a3, a4, a5);
-                        vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sx[q], K[q]);
+                        vde_tiles<T, true>(a1, a2, a3, a4, a5, jk.fu, Sx[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[q][rt][ct] = Sx[q][rt][ct] + hh * K[q][rt][ct];
+                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sm[q][rt][ct] = (rt == 3 && ct == 0) ? T(0) : Sx[q][rt][ct] + hh * K[q][rt][ct];
                         }
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         T a1, a2, a3, a4, a5;
                         jac_tiles_ev(jk, ev[q] + st * 14 + 7, ev[q][ire + sre * (2 * st + 1)], t2[q], a1, a2, a3, a4, a5);
-                        vde_tiles(a1, a2, a3, a4, a5, jk.fu, Sm[q], K[q]);
+                        vde_tiles<T, true>(a1, a2, a3, a4, a5, jk.fu, Sm[q], K[q]);
                     }
                     NMPC_UNROLL for (int q = 0; q < PB; q++) {
                         NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
-                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) Sx[q][rt][ct] += hstep * K[q][rt][ct];
+                            NMPC_UNROLL for (int ct = 0; ct < 3; ct++) { if (!(rt == 3 && ct == 0)) Sx[q][rt][ct] += hstep * K[q][rt][ct]; }    // (3,0): d omega / d q = 0
                         }
                     }
                 }
@@ -267,7 +267,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                             NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
                                 const T bq = ev[q][EV_B + (natR[rt] >= 0 ? natR[rt] : 0)];
                                 const T c15 = natR[rt] >= 0 ? bq : ((rt == 3 && ta == 3) ? T(1) : T(0));
-                                a[(rt * 3 + 0) * 16] = Sx[q][rt][0];
+                                if (rt < 3) a[(rt * 3 + 0) * 16] = Sx[q][rt][0];          // (tile (3,0) is zero and never read)
                                 a[(rt * 3 + 1) * 16] = tc < 3 ? Sx[q][rt][1] : c15;
                                 a[(rt * 3 + 2) * 16] = Sx[q][rt][2];
                             }
