@@ -667,7 +667,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
                     T a0 = 0, a1 = 0, aB = 0;
                     NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                        a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                        if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);     // tile (3,0) of Abar (d omega+ / d q, homogeneous row) is zero
                         a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
                         aB = mfma44(Pt[kt][it], Bt[kt], aB);
                     }
@@ -753,7 +753,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                                a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                                if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
                                 a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
                             }
                         }
@@ -920,7 +920,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         // the part of Abar xbar that does not wait for u
                         T xn[4];
                         xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
-                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);
                         // v = Mbar xbar (two chains), u = -L^-T v
                         const T v = mfma44(cMT[i][2], xt[2], mfma44(cMT[i][0], xt[0], T(0)))
                                   + mfma44(cMT[i][3], xt[3], mfma44(cMT[i][1], xt[1], T(0)));
@@ -1225,7 +1225,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                             T an[4];
                             an[0] = pit[0];
                             an[1] = dt_v * pit[0] + pit[1];
-                            an[2] = mfma44(Aq0[2], pit[2], mfma44(Aq0[0], pit[0], T(0))) + mfma44(Aq0[3], pit[3], mfma44(Aq0[1], pit[1], T(0)));
+                            an[2] = mfma44(Aq0[2], pit[2], mfma44(Aq0[0], pit[0], T(0))) + mfma44(Aq0[1], pit[1], T(0));       // (Aq0[3] = 0)
                             an[3] = mfma44(Aq1z[2], pit[2], mfma44(Aq1z[0], pit[0], T(0))) + mfma44(Aq1z[3], pit[3], mfma44(Aq1z[1], pit[1], T(0)));
                             NMPC_UNROLL for (int t = 0; t < 4; t++) {
                                 const T v = an[t] - mfma44(cMn[i][t], mvt, T(0));
@@ -1325,7 +1325,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                         T *ivk = tIV + k * IV_ROWS;
                         T xn[4];
                         xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
-                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3z[it], xt[3], mfma44(AT2[it], xt[2], xn[it]));
+                        NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3z[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);
                         const T v = mfma44(cMT[i][2], xt[2], mfma44(cMT[i][0], xt[0], T(0)))
                                   + mfma44(cMT[i][3], xt[3] + one15, mfma44(cMT[i][1], xt[1], T(0)));
                         const T ut = -mfma44(cZ[i], v, T(0));
