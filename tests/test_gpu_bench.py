@@ -1,0 +1,49 @@
+"""bench.py on the GPU box: the contract line of the default single-GPU run and the RCCL path of the multi-GPU run
+rehearsed with one rank (the 8-GPU run itself is the driver's)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _run(extra_env, *args):
+    env = dict(os.environ, **extra_env)
+    out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=600,
+                         cwd=str(ROOT), env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+def test_default_line_carries_the_contract_fields():
+    d = _run({}, "--steps", "20", "--warmup", "3", "--no-secondary")
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["n_gpus"] == 1 and d["steps"] == 20 and d["warmup"] == 3 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["data"] == "synthetic" and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0 < r["frac"] < 1
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) / d["value"] < 1e-6
+    assert r["kernel_ms"] <= d["ms_per_step"] * 1.02            # device time of a step cannot exceed its wall time
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0
+    assert d["status_histogram"][0] == 4096
+
+
+def test_rccl_path_with_one_rank():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(NMPC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    d = _run(env, "--steps", "24", "--warmup", "4", "--no-cpu-baseline")
+    assert d["n_gpus"] == 1 and "all-gather" in d["config"]["parallelism"]
+    assert d["secondary"]["gather_every_8"]["value"] > 0         # the batched exchange ran too
+    assert d["status_histogram"][0] == 4096
