@@ -748,29 +748,32 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     // accumulation, so the result tiles never pass through the vector ALU.  (Element [15][15], the
                     // constant of the cost-to-go, just accumulates: nothing reads it.)
                     T Pn[4][4];
+                    // Only the ten tiles on and above the diagonal are assembled and updated: Pbar is kept EXACTLY symmetric (the
+                    // diagonal tiles averaged with their transposes, the tiles below as transposes - X' I transposes a tile).
+                    // Computed independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
+                    // contracted by the recursion: it grows by rho(A)^2 per stage (see team_as).
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                         T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
-                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
+                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                                 if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                                a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                                if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
                             }
                         }
                         Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
-                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0));
+                        Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
                         Pn[2][jt] = a2;
                         Pn[3][jt] = a3;
-                    }
-                    // the (q,w) x (p,v) tiles are the transposes of the (p,v) x (q,w) ones (Qbar included: it is
-                    // symmetric): an MFMA with the identity
-                    NMPC_UNROLL for (int it = 2; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
                     }
                     T Mn[4];
                     NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M[t];
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+                        NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+                    }
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
+                    NMPC_UNROLL for (int it = 1; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
                     }
                     if (tP && k <= wnd && pol && st_ok) {
                         T *cp = tP + (size_t)k * TP_ROWS + r;

@@ -437,6 +437,16 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 NMPC_WSYNC();
                 T Lf[10];
                 NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
+#if defined(NMPC_DEBUG_NAN) && defined(__HIP_DEVICE_COMPILE__) && defined(NMPC_PROFILE)
+                {   // diagnostic build (tools/dev/nan_probe.py): first stage at which a NaN reaches the factor stage, and where
+                    bool fa = false, fp = false, fh = false;
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) fa |= !(Aq0[t] == Aq0[t]) || !(Aq1[t] == Aq1[t]) || !(Bt[t] == Bt[t]);
+                    NMPC_UNROLL for (int a_ = 0; a_ < 4; a_++) { NMPC_UNROLL for (int b_ = 0; b_ < 4; b_++) fp |= !(Pt[a_][b_] == Pt[a_][b_]); }
+                    NMPC_UNROLL for (int i = 0; i < 10; i++) fh |= !(Lf[i] == Lf[i]);
+                    const int code = (__ballot(fa) & team_mask) ? 1 : ((__ballot(fp) & team_mask) ? 2 : ((__ballot(fh) & team_mask) ? 3 : 0));
+                    if (prof_acc_[5] == 0 && code) prof_acc_[5] = 1000000 + pass * 100000 + k * 100 + code;
+                }
+#endif
                 // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt)).  Tile (3,0) of Abar -
                 // d omega+ / d q and the homogeneous row - is identically zero (the body rates do not depend on the attitude):
                 // its products are left out here, in the (q,w) x (q,w) block below and in the forward sweep (94 MFMAs per stage)
@@ -476,27 +486,22 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 if (!LAST) {
                     T qcol[4], qrow[4];       // column / row 15 of Qbar: the stage gradient, zero elsewhere (read from a zero slot)
                     NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
-                    // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators
+                    // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators: the ten tiles on and above
+                    // the diagonal only (see the update below)
                     NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                         T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
-                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] : T(0)) + qrow[jt];
+                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
                         if (jt >= 2) {
                             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                                 if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                                if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);     // tile (3,2) is the transpose of (2,3), below
+                                if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
                             }
                         }
                         Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
-                        Pn[1][jt] = dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0));
+                        Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
                         Pn[2][jt] = a2;
                         Pn[3][jt] = a3;
                     }
-                    NMPC_UNROLL for (int it = 2; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < 2; jt++) Pn[it][jt] = mfma44(Pn[jt][it], Idt, T(0));
-                    }
-                    Pn[3][2] = mfma44(Pn[2][3], Idt, T(0));    // (computing only the upper tiles and transposing the UPDATED ones - 95
-                                                               // MFMAs instead of 100 - measured no faster: the transposes then sit
-                                                               // at the end of the stage's dependency chain)
                 }
                 // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
                 // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
@@ -551,8 +556,19 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 if (!LAST) {
                     T Mn[4];
                     NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
+                    // Pbar is kept EXACTLY symmetric: products for the tiles on and above the diagonal, the diagonal tiles
+                    // averaged with their transposes, the tiles below as transposes (X' I transposes a tile).  Computed
+                    // independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
+                    // contracted by the recursion: it grows by rho(A)^2 per stage - harmless for the reference's vehicle
+                    // (rho = 1.04), a NaN after ~30 stages where the discretised open loop is violently unstable (dt = 0.1 with
+                    // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The row form, the
+                    // lane kernel and the oracle carry one triangle of P only.
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+                        NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+                    }
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
+                    NMPC_UNROLL for (int it = 1; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
                     }
                     if (tP && k <= wnd) {
                         T *cp = tP + (size_t)k * TP_ROWS + r;

@@ -270,6 +270,38 @@ def test_randomised_vehicle_tuning_and_references(seed):
     np.testing.assert_allclose(out2["u0"][ok2], ref2["u0"][ok2], rtol=0, atol=10 * TOL_U * scale)
 
 
+@pytest.mark.parametrize("polish", [1, 0])
+def test_unstable_discretised_open_loop_keeps_the_riccati_recursion_symmetric(polish):
+    """dt = 0.1 with ONE integrator step, a light vehicle with a small inertia and body rates of several rad/s: the
+    discretised open loop has a spectral radius of ~2.  The tile form of the backward sweep used to compute tile (i,j) and
+    tile (j,i) of the cost-to-go independently; their rounding difference - an antisymmetric perturbation the recursion does
+    not contract - grew by rho^2 per stage and ended as NaN / QP failures on 19 of 511 instances after 31 stages (and as
+    wrong commands with status 0 on others), where the row form, the lane kernel and the oracle - one triangle of P - were
+    fine (found by tools/dev/fuzz_parity.py, draw 21).  P is now kept exactly symmetric."""
+    over = dict(N=31, dt=0.1, mass=0.4738978976479069, inertia=[0.0017, 0.006, 0.012],
+                rotor_x=[0.4541, 0.0, -0.4541, 0.0], rotor_y=[0.0, 0.4541, 0.0, -0.4541], rotor_z=[-0.0141, 0.0141, -0.0141, 0.0141],
+                lbu=[0.0452] * 4, ubu=[2.0395] * 4,
+                W=[0.1868, 4.7625, 0.1212, 70.9006, 3.7842, 57.0244, 0.0357, 32.6734, 12.5504, 0.1446, 29.7859, 5.8384, 0.409,
+                   11.6702, 0.8986, 3.7607, 0.0134],
+                W_e=[0.127, 13.7797, 13.6895, 2.7246, 3.6848, 4.8743, 0.2726, 140.7136, 0.5401, 23.0029, 17.7842, 0.149, 23.2557],
+                levenberg_marquardt=0.0, sim_num_steps=1, lm_scaled_by_dt=1, cost_scaled_by_dt=1,
+                flags=_lib.FLAG_TEAM_MAPPING, max_batch=512, qp_polish=polish)
+    from tests.oracle_solver import OracleOcpSolver
+    s = make_solver(**over)
+    c = OracleOcpSolver(s.config).c
+    c.qp_polish = polish
+    B = 511
+    x0 = sample_x0(B, 9021, **WILD)
+    hov = over["mass"] * 9.81 / 4.0
+    yref = np.zeros((31, 17)); yref[:, 2] = 1.0; yref[:, 6] = 1.0; yref[:, 13:] = hov
+    ye = yref[0, :13].copy()
+    out = s.solve_batch(x0, yref, ye)
+    ref = O.solve_batch(c, x0, yref, ye, nthreads=8)
+    assert (ref["status"] == 0).all()
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    np.testing.assert_allclose(out["u0"], ref["u0"], rtol=0, atol=1e-7)
+
+
 @pytest.mark.parametrize("N,cond_N", [(20, 5), (20, 3), (7, 5)])
 def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
     """SURVEY 8a7 on the GPU: k_cond_ipm (condense -> IPM on dense blocks -> expand) vs the oracle's
