@@ -789,8 +789,8 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         __syncthreads();   // L, m of every stage (written by lane 0) visible to the team
         bool pol_fail = false;
         if (act && !ok) {
-            if (nanp) { status = 1; mode = M_DONE; }
-            else if (pol) pol_fail = true;              // active-set pass: give up this attempt
+            if (pol) pol_fail = true;                   // active-set pass (also one that produced a NaN, see team_as): give up this attempt
+            else if (nanp) { status = 1; mode = M_DONE; }
             else { status = 4; mode = M_DONE; }
         }
         const bool act2 = mode != M_DONE, st_ok2 = act2 && valid;

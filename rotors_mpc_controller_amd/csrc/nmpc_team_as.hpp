@@ -597,7 +597,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         __syncthreads();
         bool pol_fail = false;
         if (pol && !ok) {
-            if (nanp) { status = 1; mode = M_DONE; }
+            // A NaN pivot with nothing pinned (first pass) means NaN data: status 1.  In a later pass it can be the pinned
+            // recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per
+            // stage there - and is one more way for the attempt to fail: the interior point iteration takes over, as in the
+            // oracle (ocpqp_polish breaks out of a pass that produced a NaN)
+            if (nanp && pass == 0) { status = 1; mode = M_DONE; }
             else pol_fail = true;                       // give up this attempt
         }
         const bool pol2 = mode == M_POL;

@@ -270,15 +270,18 @@ def test_randomised_vehicle_tuning_and_references(seed):
     np.testing.assert_allclose(out2["u0"][ok2], ref2["u0"][ok2], rtol=0, atol=10 * TOL_U * scale)
 
 
-@pytest.mark.parametrize("polish", [1, 0])
-def test_unstable_discretised_open_loop_keeps_the_riccati_recursion_symmetric(polish):
+@pytest.mark.parametrize("polish,N", [(1, 31), (0, 31), (1, 120)])
+def test_unstable_discretised_open_loop_keeps_the_riccati_recursion_symmetric(polish, N):
     """dt = 0.1 with ONE integrator step, a light vehicle with a small inertia and body rates of several rad/s: the
     discretised open loop has a spectral radius of ~2.  The tile form of the backward sweep used to compute tile (i,j) and
     tile (j,i) of the cost-to-go independently; their rounding difference - an antisymmetric perturbation the recursion does
     not contract - grew by rho^2 per stage and ended as NaN / QP failures on 19 of 511 instances after 31 stages (and as
     wrong commands with status 0 on others), where the row form, the lane kernel and the oracle - one triangle of P - were
-    fine (found by tools/dev/fuzz_parity.py, draw 21).  P is now kept exactly symmetric."""
-    over = dict(N=31, dt=0.1, mass=0.4738978976479069, inertia=[0.0017, 0.006, 0.012],
+    fine (found by tools/dev/fuzz_parity.py, draw 21).  P is now kept exactly symmetric.
+    N = 120: long saturated stretches of this plant are an open loop in the pinned recursion of an active-set pass (P grows
+    by rho^2 per stage) and a pass can end in a NaN pivot; that is an attempt that failed - the interior point iteration
+    takes over, as in the oracle - not status 1 (30 of 511 instances before the fix)."""
+    over = dict(N=N, dt=0.1, mass=0.4738978976479069, inertia=[0.0017, 0.006, 0.012],
                 rotor_x=[0.4541, 0.0, -0.4541, 0.0], rotor_y=[0.0, 0.4541, 0.0, -0.4541], rotor_z=[-0.0141, 0.0141, -0.0141, 0.0141],
                 lbu=[0.0452] * 4, ubu=[2.0395] * 4,
                 W=[0.1868, 4.7625, 0.1212, 70.9006, 3.7842, 57.0244, 0.0357, 32.6734, 12.5504, 0.1446, 29.7859, 5.8384, 0.409,
@@ -293,13 +296,18 @@ def test_unstable_discretised_open_loop_keeps_the_riccati_recursion_symmetric(po
     B = 511
     x0 = sample_x0(B, 9021, **WILD)
     hov = over["mass"] * 9.81 / 4.0
-    yref = np.zeros((31, 17)); yref[:, 2] = 1.0; yref[:, 6] = 1.0; yref[:, 13:] = hov
+    yref = np.zeros((N, 17)); yref[:, 2] = 1.0; yref[:, 6] = 1.0; yref[:, 13:] = hov
     ye = yref[0, :13].copy()
     out = s.solve_batch(x0, yref, ye)
     ref = O.solve_batch(c, x0, yref, ye, nthreads=8)
-    assert (ref["status"] == 0).all()
-    np.testing.assert_array_equal(out["status"], ref["status"])
-    np.testing.assert_allclose(out["u0"], ref["u0"], rtol=0, atol=1e-7)
+    ok = ref["status"] == 0
+    assert ok.all() if N == 31 else ok.sum() >= 480          # at N = 120 the oracle itself gives up on a few instances
+    # no failure the oracle does not have (N = 120: one instance needs 40 interior-point iterations in the oracle and ends as
+    # NaN after 42 on the GPU, with or without the active-set passes - allowed for; before the fix it was 30)
+    assert (out["status"][ok] != 0).sum() <= (0 if N == 31 else 2)
+    both = ok & (out["status"] == 0)
+    # N = 120: most instances end on the interior-point iterate of a very badly conditioned QP (the two IPMs differ at 4e-3 there)
+    np.testing.assert_allclose(out["u0"][both], ref["u0"][both], rtol=0, atol=1e-7 if N == 31 else 2e-2)
 
 
 @pytest.mark.parametrize("N,cond_N", [(20, 5), (20, 3), (7, 5)])

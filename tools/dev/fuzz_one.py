@@ -28,6 +28,7 @@ over = dict(N=N, dt=float(rng.choice([0.01, 0.02, 0.05, 0.08, 0.1])), mass=mass,
 for kv in sys.argv[2:]:
     k, v = kv.split("=")
     over[k] = type(over[k])(float(v)) if not isinstance(over[k], list) else over[k]
+N = over["N"]
 print({k: (v if not isinstance(v, list) else [round(x, 4) for x in v]) for k, v in over.items()})
 s = NmpcOcpSolver(_lib.default_config(**over))
 c = OracleOcpSolver(s.config).c
@@ -84,3 +85,13 @@ for i in np.argsort(-dd)[:4]:
     yr_i = yref if yref.ndim == 2 else yref[i]; ye_i = ye if ye.ndim == 1 else ye[i]
     jg = qp_check(c, x0[i], yr_i, ye_i, out["x"][i], out["u"][i]); jo = qp_check(c, x0[i], yr_i, ye_i, ref["x"][i], ref["u"][i])
     print(f"inst {i} |du0| {dd[i]:.2e}: gpu J {jg[0]:.10e} dyn res {jg[1]:.1e} viol {jg[2]:.1e} | oracle J {jo[0]:.10e} dyn res {jo[1]:.1e} viol {jo[2]:.1e} | max|A| {jg[3]:.1e} max|B| {jg[4]:.1e}")
+
+# warm-started second solve, each side from its own first solution (as fuzz_parity.py does)
+c.qp_polish = 1
+out2 = s.solve_batch(x0, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
+ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=16)
+mm = np.nonzero(out2["status"] != ref2["status"])[0]
+print("warm solve: gpu", np.bincount(out2["status"], minlength=5), "oracle", np.bincount(ref2["status"], minlength=5), "mismatching instances", mm[:10])
+for i in mm[:4]:
+    print(f"  inst {i}: cold status gpu {out['status'][i]} oracle {ref['status'][i]} | warm gpu {out2['status'][i]} oracle {ref2['status'][i]} iters(oracle) {ref2['iters'][i]} "
+          f"max|x_init| gpu {np.abs(out['x'][i]).max():.3g} oracle {np.abs(ref['x'][i]).max():.3g} |dx_init| {np.abs(out['x'][i] - ref['x'][i]).max():.2e}")
