@@ -1419,13 +1419,16 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
         // far as the compiler knows, and one exposed global round trip per stage dominated this sweep
         constexpr int CH = 8;
         const int uoff = (from_ua ? 12 : 0) + j;
-        // every instance of this wave ended on an accepted active-set pass: its forward sweep already
-        // left xhat_k (the same recursion on the same inputs), so the step is applied stage-parallel
-        const bool fast = __ballot(valid && !from_ua) == 0;
-        if (fast) {
+        // an instance that ended on an accepted active-set pass: its forward sweep already left xhat_k (the same
+        // recursion on the same inputs), so the step is applied stage-parallel.  The choice is per TEAM - taken per wave
+        // (all four instances accepted, or the rollout below for everybody) it made the last bits of an accepted
+        // instance's state trajectory depend on how its wave-mates ended (found by tools/dev/fuzz_perm.py)
+        const bool fast = from_ua;
+        const bool any_fast = __ballot(valid && from_ua) != 0, any_slow = __ballot(valid && !from_ua) != 0;
+        if (any_fast) {
             // the workspace iterate (xl, ul) is not read again after this kernel: the new iterate goes
             // straight to the caller's arrays (13- and 4-element runs per team), or nowhere but u0
-            u0_new = NMPC_UL0( j) + tIV[uoff];
+            if (fast) u0_new = NMPC_UL0( j) + tIV[uoff];
             if (out.x_out || out.u_out) {
                 for (int k0 = 0; k0 <= N; k0 += CH) {
                     T uv[CH], ulv[CH], xlv[CH], xhv[CH];
@@ -1438,7 +1441,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                     NMPC_UNROLL for (int i = 0; i < CH; i++) {
                         const int k = k0 + i;
-                        if (k <= N && valid) {
+                        if (k <= N && valid && fast) {
                             if (out.x_out && rowl)
                                 out.x_out[((size_t)inst * (N + 1) + k) * NX + rr] = xlv[i] + (k > 0 ? xhv[i] : T(0));
                             if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = ulv[i] + uv[i];
@@ -1446,8 +1449,9 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     }
                 }
             }
-            outputs_done = true;
-        } else {
+            outputs_done = fast;
+        }
+        if (any_slow) {
         if (SHARED && MF) rows_from_lds();
         for (int k0 = 0; k0 < N; k0 += CH) {
             T uv[CH], ulv[CH], xlv[CH];
@@ -1472,7 +1476,7 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                     NMPC_UNROLL for (int cc = 0; cc < NZ; cc++) a += Adrow[cc] * sXh[p * 16 + 6 + cc];
                     NMPC_UNROLL for (int ii = 0; ii < NU; ii++) a += Brow[ii] * du[ii];
                     dx = a;
-                    if (upd && valid) {
+                    if (upd && valid && !fast) {
                         if (cmpl) NMPC_TST(w.ul, ULR, k * NU + j, ulv[i] + u);
                         if (rowl) NMPC_TST(w.xl, XLR, (k + 1) * NX + rr, xlv[i] + dx);
                     }
@@ -1481,15 +1485,17 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
             }
         }
         }
-        if (!fast) {
+        if (any_slow) {
             // NaN anywhere in the step poisons the instance: reduce the flag over the team
             // (an accepted active-set pass has been checked already)
             sXh[r] = (dx == dx && !bad) ? T(0) : T(1);
             __syncthreads();
             T nb = 0;
             NMPC_UNROLL for (int l = 0; l < NX; l++) nb += sXh[l];
-            if (nb > T(0) && upd) status = 1;
-            u0_new = NMPC_TLD(w.ul, ULR, j);
+            if (!fast) {
+                if (nb > T(0) && upd) status = 1;
+                u0_new = NMPC_TLD(w.ul, ULR, j);
+            }
         }
     }
     NMPC_STAMP(6)
