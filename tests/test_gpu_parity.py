@@ -310,6 +310,29 @@ def test_unstable_discretised_open_loop_keeps_the_riccati_recursion_symmetric(po
     np.testing.assert_allclose(out["u0"][both], ref["u0"][both], rtol=0, atol=1e-7 if N == 31 else 2e-2)
 
 
+@pytest.mark.parametrize("share", [1, 0])
+def test_results_do_not_depend_on_wave_mates_with_trajectories_and_second_launch(share):
+    """A batch in which some instances end on an accepted active-set pass and others on the interior-point iterate of the
+    second launch (wild set), solved as drawn and permuted, trajectories wanted: every output bit-identical.  The general
+    kernel used to choose its output path per wave - an accepted instance's state trajectory depended in its last bits on
+    how its wave-mates had ended (found by tools/dev/fuzz_perm.py)."""
+    s = make_solver(flags=_lib.FLAG_TEAM_MAPPING | share, max_batch=512)
+    B = 511
+    x0 = np.concatenate([sample_x0(300, 71, **WILD), sample_x0(B - 300, 72, **AGGRESSIVE)])
+    yref, ye = hover(s.config)
+    a = s.solve_batch(x0, yref, ye, want_traj=True)
+    st = s.stats()
+    assert st["iter_max"] > 0 and st["n_polished"] > B // 2          # both ways of ending are present
+    perm = np.random.default_rng(73).permutation(B)
+    b = s.solve_batch(x0[perm], yref, ye, want_traj=True)
+    for key in ("u0", "status", "x", "u"):
+        np.testing.assert_array_equal(a[key][perm], b[key])
+    a2 = s.solve_batch(x0, yref, ye, x_init=a["x"], u_init=a["u"], want_traj=True)
+    b2 = s.solve_batch(x0[perm], yref, ye, x_init=a["x"][perm], u_init=a["u"][perm], want_traj=True)
+    for key in ("u0", "status", "x", "u"):
+        np.testing.assert_array_equal(a2[key][perm], b2[key])
+
+
 @pytest.mark.parametrize("N,cond_N", [(20, 5), (20, 3), (7, 5)])
 def test_partial_condensing_kernel_matches_oracle_and_the_fast_path(N, cond_N):
     """SURVEY 8a7 on the GPU: k_cond_ipm (condense -> IPM on dense blocks -> expand) vs the oracle's

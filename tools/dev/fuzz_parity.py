@@ -17,6 +17,7 @@ from tests.oracle_solver import OracleOcpSolver  # noqa: E402
 WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
 n_draws = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+MAPPING = "lane" if "--lane" in sys.argv else ("cond" if "--cond" in sys.argv else "team")     # the fidelity kernels: plain IPM on both sides
 worst = 0.0
 bad = 0
 for seed in range(first, first + n_draws):
@@ -36,9 +37,20 @@ for seed in range(first, first + n_draws):
                 lm_scaled_by_dt=int(rng.integers(0, 2)), cost_scaled_by_dt=int(rng.integers(0, 2)),
                 flags=_lib.FLAG_TEAM_MAPPING | int(rng.integers(0, 2)), max_batch=B,
                 qp_polish_ckpt=int(rng.choice([0, 1, 4, 12, 100])))
+    if MAPPING != "team":
+        over.pop("qp_polish_ckpt")
+        over.update(qp_polish=0, flags=(over["flags"] & 1) | (_lib.FLAG_CONDENSED_QP if MAPPING == "cond" else 0))
+        if MAPPING == "cond":
+            over.update(qp_cond_N=int(rng.choice([2, 3, 5])))
+            if N > 40 or over["sim_num_steps"] > 2:
+                print(f"seed {seed:3d}: skipped (condensed fidelity kernel: N <= 40)")
+                continue
+        B = min(B, 130); over["max_batch"] = B
     s = NmpcOcpSolver(_lib.default_config(**over))
     c = OracleOcpSolver(s.config).c
-    c.qp_polish = 1
+    c.qp_polish = 1 if MAPPING == "team" else 0
+    if MAPPING == "cond":
+        c.qp_cond_N = over["qp_cond_N"]
     dist = [NEAR_HOVER, AGGRESSIVE, WILD][int(rng.integers(0, 3))]
     x0 = sample_x0(B, 9000 + seed, **dist)
     per_inst = bool(rng.integers(0, 2))
@@ -73,7 +85,7 @@ for seed in range(first, first + n_draws):
     flag = "" if (sm == 0 and sm2 == 0 and d1 < 1e-9 and d2 < 1e-8 and dx < 1e-8) else "   <-- CHECK"
     bad += bool(flag)
     worst = max(worst, d1, d2)
-    print(f"seed {seed:3d} N={N:2d} B={B:3d} steps={over['sim_num_steps']} share={over['flags'] & 1} ckpt={over['qp_polish_ckpt']:3d} "
+    print(f"seed {seed:3d} N={N:2d} B={B:3d} steps={over['sim_num_steps']} share={over['flags'] & 1} ckpt={over.get('qp_polish_ckpt', 0):3d} "
           f"dist={'NAW'[[NEAR_HOVER, AGGRESSIVE, WILD].index(dist)]} ok {int(ok.sum())}/{B}: cold |du0| {d1:.1e} |dx| {dx:.1e} "
           f"warm |du0| {d2:.1e} status mismatches {sm}+{sm2} passes max {st['polish_max']} ipm max {st['iter_max']}{flag}", flush=True)
     s.close()
