@@ -76,8 +76,15 @@ for seed in range(first, first + n_draws):
     if not traj:
         o1 = s.solve_batch(x0, yref, ye)
         assert np.array_equal(o1["u0"], out["u0"]) and np.array_equal(o1["status"], out["status"]), "u0 differs with / without trajectories"
-    out2 = s.solve_batch(x0, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
-    ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=16)
+    if "--random-init" in sys.argv:      # an arbitrary (dynamically inconsistent) linearisation trajectory, the same on both sides
+        xi = np.tile(x0[:, None, :], (1, N + 1, 1)) + rng.normal(0, 0.3, (B, N + 1, 13)); xi[:, 0] = x0
+        qn = np.linalg.norm(xi[:, :, 6:10], axis=2, keepdims=True); xi[:, :, 6:10] /= np.where(qn > 0, qn, 1.0)
+        ui = rng.uniform(over["lbu"][0], over["ubu"][0], (B, N, 4))
+        out2 = s.solve_batch(x0, yref, ye, x_init=xi, u_init=ui, want_traj=True)
+        ref2 = O.solve_batch(c, x0, yref, ye, x_init=xi, u_init=ui, want_traj=True, nthreads=16)
+    else:
+        out2 = s.solve_batch(x0, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
+        ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=16)
     sm2 = int((out2["status"] != ref2["status"]).sum())
     ok2 = ok & (ref2["status"] == 0) & (out2["status"] == 0)
     d2 = float(np.abs(out2["u0"][ok2] - ref2["u0"][ok2]).max()) / scale if ok2.any() else 0.0
