@@ -709,6 +709,18 @@ __device__ __forceinline__ void team_ipm(const Consts<T> &c, const Work<T> &w, c
                 T Lf[10], mv[NU];
                 NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
                 NMPC_UNROLL for (int i = 0; i < NU; i++) mv[i] = sHg[10 + i];
+#if defined(NMPC_DEBUG_NAN) && defined(__HIP_DEVICE_COMPILE__) && defined(NMPC_PROFILE)
+                {   // diagnostic build (tools/dev/nan_probe.py): first (iteration, stage) at which a non-finite value reaches the factor stage
+                    auto nf = [](T v) { return !(v - v == T(0)); };
+                    bool fa = false, fp = false, fh = false, fd = nf(D_a) || nf(rhat_a);
+                    NMPC_UNROLL for (int t = 0; t < 4; t++) fa |= nf(Aq0[t]) || nf(Aq1[t]) || nf(Bt[t]);
+                    NMPC_UNROLL for (int a_ = 0; a_ < 4; a_++) { NMPC_UNROLL for (int b_ = 0; b_ < 4; b_++) fp |= nf(Pt[a_][b_]); }
+                    NMPC_UNROLL for (int i = 0; i < 10; i++) fh |= nf(Lf[i]);
+                    const unsigned long long tm_ = 0x000F000F000F000Full << (4 * team);
+                    const int code = (__ballot(fa) & tm_) ? 1 : ((__ballot(fd) & tm_) ? 4 : ((__ballot(fp) & tm_) ? 2 : ((__ballot(fh) & tm_) ? 3 : 0)));
+                    if (prof_acc_[7] >= 0 && code) prof_acc_[7] = -(1000000 + it * 10000 + k * 10 + code);
+                }
+#endif
                 NMPC_UNROLL for (int jj = 0; jj < NU; jj++) {
                     T d = Lf[lidx(jj, jj)];
                     NMPC_UNROLL for (int l = 0; l < jj; l++) d -= Lf[lidx(jj, l)] * Lf[lidx(jj, l)];
