@@ -96,7 +96,20 @@ typedef struct nmpc_config {
                                   (the first pass of an attempt keeps at most two): the next pass refactorises only
                                   stages <= the highest stage whose pin set changed when a current checkpoint
                                   covers it, else the whole horizon.  0 = always the whole horizon                     */
-    int32_t reserved_;
+    int32_t qp_maxiter_status; /* [UPSTREAM U10] status of a solve whose QP hits qp_iter_max: 0 = tolerated (current acados SQP_RTI),
+                                  2 = NMPC_MAXITER is returned (some acados versions; the caller then discards the command and
+                                  cold-starts, controller.py:448-450, nodes/mpc_controller_node:124)                           */
+    /* Accuracy certificate of the Riccati factorisations (FP64 tile kernels; this build's own device, not HPIPM's).
+     * g = max_k |B_k' P_{k+1} B_k| of a backward sweep, against g of the FIRST factorisation of the solve: pinned inputs
+     * (active-set pass) or heavily penalised ones (late interior-point iterations) leave stretches of the horizon open loop, on
+     * an unstable plant P then grows by rho(A)^2 per stage and the recursion loses about 1e-15 * growth of relative accuracy.
+     * A sweep with g > qp_growth_max * g_first is not trusted: an active-set pass is not accepted (no further attempt), an
+     * interior-point iteration is not taken - the QP ends at its iterate: status 0 if mu <= qp_acc_comp and the stationarity
+     * factor <= qp_acc_stat, NMPC_QP_FAILURE otherwise.  0 = certificate off.  Never reached with the reference's vehicle.   */
+    double qp_growth_max;      /* default 1e6 */
+    double qp_acc_comp;        /* default 1e-8  ([UPSTREAM] HPIPM's default complementarity tolerance) */
+    double qp_acc_stat;        /* default 1e-8 */
+    double qp_tol_step;        /* convergence also needs the last step max |alpha d| / (ubu - lbu) <= this; default 1e-3, 0 = off */
 } nmpc_config;
 
 typedef struct nmpc_stats {
@@ -168,6 +181,9 @@ const int32_t *nmpc_device_iterations(nmpc_solver *s);
  * > 0: the instance ended on an accepted active-set solution after that many passes, <= 0: it did not
  * (interior-point result), the magnitude being the passes spent                                          */
 const int32_t *nmpc_device_passes(nmpc_solver *s);
+
+/* synchronises, then copies the two arrays above to the host: iterations [n], passes [n] (either may be NULL), n <= max_batch */
+int nmpc_get_counts(nmpc_solver *s, int n, int32_t *iterations, int32_t *passes);
 
 /* synchronises, then fills iteration / status histograms and kernel times of the last solve */
 int nmpc_get_stats(nmpc_solver *s, nmpc_stats *out);

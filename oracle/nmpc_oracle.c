@@ -66,6 +66,11 @@ void orc_default_config(orc_config *c)
     c->qp_polish_mu = 1.0;      /* >= mu0: the first attempt is a pure active-set solve from 'all free' */
     c->qp_polish_passes = 8;   /* = the GPU library's default attempt policy (nmpc_create) */
     c->qp_polish_budget = 16;
+    c->qp_growth_max = 1e6;    /* ~1e-15 * growth of relative accuracy is lost: 1e-9 is still held */
+    c->qp_acc_comp = 1e-8;     /* [UPSTREAM] HPIPM's default res_m_max */
+    c->qp_acc_stat = 1e-8;
+    c->qp_tol_step = 1e-3;
+    c->qp_maxiter_status = 0;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -378,11 +383,12 @@ typedef struct {
  * always: vector recursion with gradient rhat, offsets bb (NULL = 0), state gradient qq
  * (NULL = 0), terminal qN (NULL = 0).  Returns 0 ok, 1 factorisation failure.           */
 static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int homogeneous,
-                            int factor, ricc_fact *f, double **Pb_store)
+                            int factor, ricc_fact *f, double *gmax)
 {
+    /* gmax (factor pass, may be NULL): max over stages and entries of |B_k' P_{k+1} B_k| - the growth certificate */
     const int N = p->N;
     double P[NX * NX], pv[NX], PA[NX * NX], Hxx[NX * NX], h[NX], gx[NX];
-    (void)Pb_store;
+    if (gmax) *gmax = 0.0;
     if (factor) memcpy(P, p->QN, sizeof(P));
     for (int i = 0; i < NX; i++) pv[i] = homogeneous ? 0.0 : p->qN[i];
     /* In the factor pass P holds P_{k+1}.  In a vector-only pass (factor == 0) the
@@ -416,9 +422,11 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
             /* Huu = R + diag(sig) + B' P B */
             for (int i = 0; i < m; i++)
                 for (int j = 0; j < m; j++) {
-                    double s = p->R[k][i * m + j] + (i == j ? sig[k][i] : 0.0);
+                    double s = 0.0;
                     for (int l = 0; l < NX; l++) s += B[l * m + i] * PB[l * m + j];
-                    L[i * m + j] = s;
+                    if (gmax && fabs(s) > *gmax) *gmax = fabs(s);
+                    if (gmax && !(s == s)) *gmax = s;              /* NaN stays NaN */
+                    L[i * m + j] = p->R[k][i * m + j] + (i == j ? sig[k][i] : 0.0) + s;
                 }
             /* Hux = S + B' P A */
             for (int i = 0; i < m; i++)
@@ -504,8 +512,11 @@ static void riccati_forward(const ocpqp *p, const ricc_fact *f, const double *dx
  * An accepted point is THE solution of the strictly convex QP; a rejected one costs one sweep and the
  * IPM simply continues.  Returns 1 if accepted (u, x overwritten; ll, lu set to the multipliers).    */
 static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, double **u, double **ll,
-                        double **lu, double *x, int max_pass, int *passes)
+                        double **lu, double *x, int max_pass, int *passes, double growth_max, double *gbase,
+                        double *growth, int *untrusted)
 {
+    /* growth certificate (orc_config.qp_growth_max): *gbase = g of the first factorisation of the solve (0 = none yet: this
+     * call's first pass sets it); a pass whose g exceeds growth_max * *gbase ends the attempt unaccepted, *untrusted = 1 */
     const int N = p->N;
     ocpqp m = *p;
     m.B = (double **)malloc(sizeof(double *) * N); m.b = (double **)malloc(sizeof(double *) * N);
@@ -567,7 +578,11 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
             }
         }
         (*passes)++;
-        if (riccati_backward(&m, zero, m.r, 0, 1, (ricc_fact *)f, NULL)) break;
+        double g = 0.0;
+        if (riccati_backward(&m, zero, m.r, 0, 1, (ricc_fact *)f, &g)) break;
+        if (*gbase == 0.0) *gbase = g;
+        if (*gbase > 0.0 && g / *gbase > *growth) *growth = g / *gbase;
+        if (growth_max > 0.0 && g > growth_max * *gbase) { *untrusted = 1; break; }
         riccati_forward(&m, f, dx0, 0, uh, xh);
         double pi[NX], pin_[NX];
         int changed = 0, nanf = 0;
@@ -668,7 +683,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         }
     }
     double rho = 1.0, mu = 0.0, pol_mu = c->qp_polish_mu;
-    int polished = 0, npolish = 0;
+    double gbase = 0.0, growth = 0.0, step_last = 0.0;
+    int polished = 0, npolish = 0, untrusted = 0;
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
     for (;;) {
         mu = 0.0;
@@ -677,9 +693,13 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 mu += ll[k][i] * (u[k][i] - p->lo[k][i]) + lu[k][i] * (p->hi[k][i] - u[k][i]);
         mu /= nc;
         if (!(mu == mu)) { status = 1; break; }
-        if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat) break;
+        if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat && (it == 0 || !(c->qp_tol_step > 0.0) || step_last <= c->qp_tol_step)) break;
         if (c->qp_polish && mu <= pol_mu && npolish < c->qp_polish_budget) {
-            if (ocpqp_polish(p, dx0, &f, u, ll, lu, x, c->qp_polish_passes, &npolish)) { polished = 1; mu = 0.0; rho = 0.0; break; }
+            int trip = 0;
+            if (ocpqp_polish(p, dx0, &f, u, ll, lu, x, c->qp_polish_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip)) {
+                polished = 1; mu = 0.0; rho = 0.0; break;
+            }
+            if (trip) { untrusted = 1; npolish = c->qp_polish_budget; }     /* the same pins would fail the same way: no further attempt */
             pol_mu *= 1e-2;
         }
         if (it >= itmax) { status = 2; break; }
@@ -691,7 +711,20 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 sig[k][i] = ll[k][i] / tl + lu[k][i] / tu;
                 rh[k][i] = p->r[k][i] - sig[k][i] * u[k][i];
             }
-        if (riccati_backward(p, sig, rh, 0, 1, &f, NULL)) { status = 3; break; }
+        {
+            double g = 0.0;
+            const int fail = riccati_backward(p, sig, rh, 0, 1, &f, &g);
+            if (!fail && gbase == 0.0) gbase = g;
+            if (!fail && gbase > 0.0 && g / gbase > growth) growth = g / gbase;
+            const int trip = !fail && c->qp_growth_max > 0.0 && !(g <= c->qp_growth_max * gbase);
+            if (fail || trip) {
+                /* this factorisation cannot be used: the QP ends at the current iterate - solved if that is within the
+                 * acceptable tolerances, a QP failure otherwise */
+                if (trip) untrusted = 1;
+                status = (mu <= c->qp_acc_comp && rho <= c->qp_acc_stat) ? 0 : (trip ? 4 : 3);
+                break;
+            }
+        }
         riccati_forward(p, &f, dx0, 0, ua, xh);
         double aaff = 1.0;
         for (int k = 0; k < N; k++)
@@ -765,8 +798,11 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
             }
         }
         if (alpha < 1e-12) { status = 3; break; }
+        step_last = 0.0;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
+                const double sw = fabs(alpha * du[k][i]) / (p->hi[k][i] - p->lo[k][i]);
+                if (sw > step_last) step_last = sw;
                 u[k][i] += alpha * du[k][i];
                 ll[k][i] += alpha * dla[k][i];
                 lu[k][i] += alpha * dua[k][i];
@@ -815,6 +851,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         }
         st->qp_iter = it; st->qp_status = status; st->res_stat = rs; st->res_eq = 0.0;
         st->res_comp = rc; st->mu = mu; st->rho = rho; st->polished = polished; st->polish_attempts = npolish;
+        st->growth = growth; st->step_last = step_last; st->untrusted = untrusted;
     }
     for (int k = 0; k < N; k++) {
         free(f.L[k]); free(f.M[k]); free(f.m[k]); free(ll[k]); free(lu[k]); free(sig[k]);
@@ -982,8 +1019,9 @@ int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
     for (int i = 0; i < (N + 1) * NX; i++) if (!(dx[i] == dx[i]) || fabs(dx[i]) > 1e300) bad = 1;
     for (int i = 0; i < N * NU; i++) if (!(du[i] == du[i]) || fabs(du[i]) > 1e300) bad = 1;
     if (bad || qps == 1) status = 1;           /* ACADOS_NAN_DETECTED */
-    else if (qps == 3) status = 4;             /* QP min step / factorisation -> QP_FAILURE */
-    else status = 0;                           /* QP max-iter is tolerated in RTI (U10) */
+    else if (qps == 3 || qps == 4) status = 4; /* QP min step / factorisation / untrusted factorisation -> QP_FAILURE */
+    else if (qps == 2) status = c->qp_maxiter_status ? 2 : 0;   /* QP max-iter: tolerated in RTI or reported (U10 switch) */
+    else status = 0;
     if (status == 0) {
         for (int i = 0; i < (N + 1) * NX; i++) xtraj[i] += dx[i];
         for (int i = 0; i < N * NU; i++) utraj[i] += du[i];

@@ -59,11 +59,25 @@ typedef struct orc_config {
     double qp_polish_mu;
     int qp_polish_passes;   /* primal-dual active-set corrections per polish attempt */
     int qp_polish_budget;   /* no further attempt once this many passes were spent */
+    /* accuracy certificate of the Riccati factorisations (this build's own device, not HPIPM's): g = max_k |B_k' P_{k+1} B_k|
+     * of a backward sweep against g of the FIRST factorisation of the solve.  Pinned (active-set pass) or heavily penalised
+     * (late interior-point iterations) inputs leave stretches of the horizon open loop; on an unstable plant P then grows by
+     * rho(A)^2 per stage and the recursion loses ~1e-15 * growth of relative accuracy.  A sweep whose g exceeds
+     * qp_growth_max * g_first is not trusted: an active-set pass is not accepted (and no further attempt is made), an
+     * interior-point iteration is not taken - the QP then ends at its current iterate, status 0 if that iterate is within the
+     * acceptable tolerances below and QP failure otherwise.  0 = certificate off.                                           */
+    double qp_growth_max;
+    double qp_acc_comp;     /* acceptable level: mu <= qp_acc_comp and rho <= qp_acc_stat (HPIPM's default tolerances) */
+    double qp_acc_stat;
+    double qp_tol_step;     /* convergence also needs the last step max|alpha d| / (ub - lb) <= this; 0 = off */
+    int qp_maxiter_status;  /* [UPSTREAM] U10 switch: status returned when the QP hits qp_iter_max: 0 = tolerated (current
+                               acados SQP_RTI), 2 = reported (some versions; the caller then discards the command,
+                               controller.py:448-450) */
 } orc_config;
 
 typedef struct orc_stats {
     int qp_iter;            /* IPM iterations taken */
-    int qp_status;          /* 0 ok, 2 max iter, 3 min step, 1 nan */
+    int qp_status;          /* 0 ok, 2 max iter, 3 min step / factorisation failure, 4 growth certificate (untrusted), 1 nan */
     double res_stat;        /* TRUE inf-norm stationarity residual at exit (recomputed) */
     double res_eq;          /* TRUE inf-norm dynamics residual at exit */
     double res_comp;        /* TRUE max complementarity product at exit */
@@ -72,6 +86,9 @@ typedef struct orc_stats {
     int hess_projected;     /* PROJECT_REDUC_HESS had to act (expected 0) */
     int polished;           /* the active-set polish was accepted */
     int polish_attempts;
+    double growth;          /* largest g / g_first seen in a factorisation of this solve */
+    double step_last;       /* max |alpha d| / (ub - lb) of the last interior-point step */
+    int untrusted;          /* 1: the growth certificate stopped an attempt or the iteration */
 } orc_stats;
 
 /* defaults = reference config/params.yaml + acados option defaults */

@@ -30,6 +30,8 @@ class OrcConfig(C.Structure):
         ("qp_mu0", C.c_double), ("qp_tau", C.c_double), ("qp_thr0", C.c_double),
         ("qp_thr0_rel", C.c_double), ("qp_gamma", C.c_double),
         ("qp_polish", C.c_int), ("qp_polish_mu", C.c_double), ("qp_polish_passes", C.c_int), ("qp_polish_budget", C.c_int),
+        ("qp_growth_max", C.c_double), ("qp_acc_comp", C.c_double), ("qp_acc_stat", C.c_double), ("qp_tol_step", C.c_double),
+        ("qp_maxiter_status", C.c_int),
     ]
 
 
@@ -39,6 +41,7 @@ class OrcStats(C.Structure):
         ("res_stat", C.c_double), ("res_eq", C.c_double), ("res_comp", C.c_double),
         ("mu", C.c_double), ("rho", C.c_double), ("hess_projected", C.c_int),
         ("polished", C.c_int), ("polish_attempts", C.c_int),
+        ("growth", C.c_double), ("step_last", C.c_double), ("untrusted", C.c_int),
     ]
 
 

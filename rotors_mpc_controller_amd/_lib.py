@@ -40,7 +40,8 @@ class NmpcConfig(C.Structure):
         ("qp_tau", C.c_double), ("qp_thr0", C.c_double), ("qp_thr0_rel", C.c_double),
         ("dtype", C.c_int32), ("device", C.c_int32), ("max_batch", C.c_int32), ("flags", C.c_uint32),
         ("qp_polish", C.c_int32), ("qp_polish_passes", C.c_int32), ("qp_polish_budget", C.c_int32),
-        ("qp_polish_mu", C.c_double), ("qp_polish_ckpt", C.c_int32), ("reserved_", C.c_int32),
+        ("qp_polish_mu", C.c_double), ("qp_polish_ckpt", C.c_int32), ("qp_maxiter_status", C.c_int32),
+        ("qp_growth_max", C.c_double), ("qp_acc_comp", C.c_double), ("qp_acc_stat", C.c_double), ("qp_tol_step", C.c_double),
     ]
 
     def update(self, **over) -> "NmpcConfig":
@@ -69,7 +70,7 @@ class NmpcStats(C.Structure):
 
 EXPORTS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
-    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_stats", "nmpc_set_timing",
+    "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_counts", "nmpc_get_stats", "nmpc_set_timing",
     "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
     "nmpc_hold_command_device", "nmpc_hold_and_step_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device",
@@ -149,6 +150,8 @@ def load() -> C.CDLL:
     lib.nmpc_device_iterations.restype = vp
     lib.nmpc_device_passes.argtypes = [vp]
     lib.nmpc_device_passes.restype = vp
+    lib.nmpc_get_counts.argtypes = [vp, C.c_int, ip, ip]
+    lib.nmpc_get_counts.restype = C.c_int
     lib.nmpc_get_stats.argtypes = [vp, C.POINTER(NmpcStats)]
     lib.nmpc_get_stats.restype = C.c_int
     lib.nmpc_set_timing.argtypes = [vp, C.c_int]

@@ -17,12 +17,14 @@ struct AsLaunch {
     TeamWork<double> tw;
     WorkList wl;
     int B, tpw, lds_stride, lstg, occ;
+    int kind = 0;               // 0: k_team_as (first attempt), 1: k_team_qp (whole QP, whole batch), 2: k_team_qp_list (work list)
+    int nlist = 0;              // workgroups of the work-list launch
     bool shared, traj;
     size_t lds_bytes;
     hipStream_t stream;
 };
 
-// enqueue k_team_as<shared, traj, occ, TI>; returns a hipError_t
+// enqueue k_team_as<shared, traj, occ, TI> / k_team_qp / k_team_qp_list (kind); returns a hipError_t
 int launch_team_as(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
 int launch_team_as(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
 

@@ -115,8 +115,10 @@ struct nmpc_solver {
     void *AB = nullptr, *bv = nullptr, *qr = nullptr, *xl = nullptr, *ul = nullptr, *LM = nullptr, *iv = nullptr, *tAB = nullptr, *tP = nullptr, *cond = nullptr;
     int32_t *d_iters = nullptr, *d_status = nullptr, *d_npol = nullptr;
     int *d_wl = nullptr;             // work list of the split FP64 path: count | done | list [Bp]
+    double *d_gbase = nullptr;       // growth certificate: first-factorisation value per instance (active-set kernel -> work-list launch)
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
+    int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
@@ -210,7 +212,11 @@ void nmpc_default_config(nmpc_config *c)
     c->qp_polish_budget = 0;
     c->qp_polish_mu = 1.0;
     c->qp_polish_ckpt = 12;
-    c->reserved_ = 0;
+    c->qp_maxiter_status = 0;
+    c->qp_growth_max = 1e6;
+    c->qp_acc_comp = 1e-8;
+    c->qp_acc_stat = 1e-8;
+    c->qp_tol_step = 1e-3;
 }
 
 static int ckpt_stages(const nmpc_config &g)
@@ -230,7 +236,7 @@ static int alloc_ws(nmpc_solver *s)
         {&s->tP, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bw : 1) * e},
         {(void **)&s->d_iters, Bp * sizeof(int32_t)},
         {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)},
-        {(void **)&s->d_wl, (Bp + 2) * sizeof(int)}};
+        {(void **)&s->d_wl, (Bp + 2) * sizeof(int)}, {(void **)&s->d_gbase, (Bp + 1) * sizeof(double)}};
     for (auto &x : a) {
         HIP_TRY(s, hipMalloc(x.p, x.n));
         s->ws_bytes += x.n;
@@ -316,6 +322,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
@@ -346,7 +353,7 @@ void nmpc_destroy(nmpc_solver *s)
     if (!s) return;
     (void)hipSetDevice(s->cfg.device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {s->d_consts, s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
+    void *ptrs[] = {s->d_gbase, s->d_consts, s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
@@ -363,6 +370,19 @@ void nmpc_destroy(nmpc_solver *s)
 const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
 
 }  // extern "C"
+
+// LDS carve of the kernels that iterate the interior point method (k_team_qp, k_team_qp_list: one wave per SIMD, 40 KB per wave):
+// stage cache rows of IP_LM_ROWS doubles, team stride 192 B past a multiple of the 256-B bank row
+static void qp_lds(const nmpc_solver *s, bool shared, AsLaunch &a)
+{
+    const int base = shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    const int per_team = 40960 / 4 / (int)sizeof(double);
+    int lstg = std::max(0, std::min(s->cfg.N, (per_team - base - 31) / IP_LM_ROWS));
+    if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
+    int stride = base + lstg * IP_LM_ROWS;
+    stride += (24 - stride % 32 + 32) % 32;
+    a.lstg = lstg; a.lds_stride = stride; a.lds_bytes = (size_t)4 * stride * sizeof(double);
+}
 
 // Default FP64 path: the active-set kernel makes the first attempt of every instance; the general kernel runs on the work
 // list of what that attempt could not settle.  TI = element type of the caller's device arrays (double, or float for
@@ -401,8 +421,15 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     al.lds_bytes = lds_as; al.stream = st;
     HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-    if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-    else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+    if (s->team_qp) {
+        AsLaunch ql = al;
+        qp_lds(s, c.shared != 0, ql);
+        ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1;
+        HIP_TRY(s, (hipError_t)launch_team_as(ql, in, out));
+    } else {
+        if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+        else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
+    }
     HIP_TRY(s, hipGetLastError());
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
     s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
@@ -421,7 +448,7 @@ static int launch_f32io(nmpc_solver *s, int B, const void *x0, const void *yref,
     w.Bp = s->Bp;
     w.AB = (double *)s->AB; w.bv = (double *)s->bv; w.qr = (double *)s->qr; w.xl = (double *)s->xl; w.ul = (double *)s->ul;
     w.LM = (double *)s->LM; w.iv = (double *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
-    w.prof = s->d_prof; w.npol = s->d_npol; w.tAB = (double *)s->tAB;
+    w.prof = s->d_prof; w.npol = s->d_npol; w.tAB = (double *)s->tAB; w.gbase = s->d_gbase;
     Inputs<float> in;
     in.x0 = (const float *)x0; in.yref = (const float *)yref; in.yref_e = (const float *)yref_e;
     in.x_init = cold ? nullptr : (const float *)x_init; in.u_init = cold ? nullptr : (const float *)u_init;
@@ -452,6 +479,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     w.prof = s->d_prof;
     w.npol = s->d_npol;
     w.tAB = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? (T *)s->tAB : nullptr;
+    w.gbase = (T *)s->d_gbase;        // (read by the FP64 tile kernels only)
     Inputs<T> in;
     in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
     in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
@@ -509,6 +537,21 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                            s->cfg.sim_num_steps <= AS_MAX_STEPS && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
         if constexpr (F64) {
             if (split) return launch_split<double>(s, c, w, in, out, tw, B, tpw, st);
+            // every other FP64 tile-form solve - qp_polish = 0, an attempt schedule that starts with interior-point iterations,
+            // NMPC_TEAM_SPLIT=0 - is ONE launch of k_team_qp (the same sweeps as the split path, nmpc_team_as.hpp)
+            if (mf && fused && s->team_qp && s->cfg.sim_num_steps <= AS_MAX_STEPS) {
+                WorkList wl;
+                wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
+                AsLaunch al;
+                al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
+                al.occ = 1; al.shared = c.shared != 0; al.traj = out.x_out != nullptr || out.u_out != nullptr;
+                al.stream = st; al.kind = 1;
+                qp_lds(s, c.shared != 0, al);
+                HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
+                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
+                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
+                return 0;
+            }
         }
 #define NMPC_LAUNCH_TEAM(W_, SH_, MF_) hipLaunchKernelGGL((k_team_ipm<T, W_, SH_, MF_>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw)
         if (mf) {
@@ -943,6 +986,18 @@ int nmpc_hold_and_step_device(nmpc_solver *s, int B, const void *u0, const int32
 
 const int32_t *nmpc_device_iterations(nmpc_solver *s) { return s ? s->d_iters : nullptr; }
 const int32_t *nmpc_device_passes(nmpc_solver *s) { return s ? s->d_npol : nullptr; }
+
+// host copies of the two arrays above, through THIS library's HIP runtime: [n] int32 each, either may be NULL
+int nmpc_get_counts(nmpc_solver *s, int n, int32_t *iterations, int32_t *passes)
+{
+    if (!s) return NMPC_EARG;
+    if (n < 0 || n > s->Bp) return s->fail(NMPC_EARG, "get_counts: n=%d outside [0, %d]", n, s->Bp);
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    HIP_TRY(s, hipDeviceSynchronize());
+    if (iterations && n) HIP_TRY(s, hipMemcpy(iterations, s->d_iters, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (passes && n) HIP_TRY(s, hipMemcpy(passes, s->d_npol, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost));
+    return 0;
+}
 
 #ifdef NMPC_PROFILE
 // diagnostic builds only (tools/profile_sweeps.py): int64 [8][Bp] DEVICE pointer and its row stride

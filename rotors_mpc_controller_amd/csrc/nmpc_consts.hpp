@@ -54,6 +54,11 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.polish_ckpt = g.qp_polish_ckpt < 0 ? 0 : (g.qp_polish_ckpt > g.N - 1 ? g.N - 1 : g.qp_polish_ckpt);
     c.polish_mu = (T)g.qp_polish_mu;
     c.kkt_tol = sizeof(T) == 8 ? (T)1e-9 : (T)1e-5;   // the oracle uses 1e-9; FP32 gradients carry ~1e-6 noise
+    c.growth_max = (T)g.qp_growth_max;
+    c.acc_comp = (T)g.qp_acc_comp;
+    c.acc_stat = (T)g.qp_acc_stat;
+    c.tol_step = (T)g.qp_tol_step;
+    c.maxiter_status = g.qp_maxiter_status;
 }
 
 

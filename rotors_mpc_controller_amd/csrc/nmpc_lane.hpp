@@ -39,7 +39,8 @@ constexpr int NZ = 7;                 // stored columns of A: q (4) and omega (3
 constexpr int AD_SIZE = 79;           // 4*10 + 3*13
 constexpr int AB_ROWS = AD_SIZE + NX * NU;   // 131 rows per stage in the AB array
 constexpr int LM_ROWS = 10 + NU * NX + NU;   // L (10, diagonal stored inverted) + M (52) + m (4)
-constexpr int IV_ROWS = 20;           // u, lam_l, lam_u, u_aff, du  (4 each)
+constexpr int IV_ROWS = 24;           // u, lam_l, lam_u, u_aff, du  (4 each) | 4 spare slots: where lanes that carry no input of
+                                      // their own store, so that no store of a tile-form sweep is predicated
 constexpr int QR_ROWS = NX + NU;      // q_k (13), r_k (4)
 
 NMPC_HD constexpr int ad_rows(int c) { return c < 4 ? 10 : 13; }
@@ -62,6 +63,10 @@ struct Consts {
     // active-set polish (team kernel only; the lane and condensed kernels are plain IPM)
     int polish, polish_passes, polish_budget, polish_ckpt;
     T polish_mu, kkt_tol;   // kkt_tol: relative acceptance tolerance of the active-set KKT check
+    // accuracy certificate of the Riccati factorisations and the exit rules that go with it (nmpc_config.qp_growth_max ...;
+    // FP64 tile kernels of nmpc_team_as.hpp; the oracle restates them in ocpqp_ipm / ocpqp_polish)
+    T growth_max, acc_comp, acc_stat, tol_step;
+    int maxiter_status;     // U10 switch: status of a QP that hits iter_max (0 tolerated, 2 reported)
 };
 
 constexpr int TAB_ROWS = 192;       // doubles per stage of the team kernels' per-instance stage block tAB
@@ -81,6 +86,7 @@ struct Work {
     int32_t *status;  // [Bp]
     int32_t *npol;    // [Bp] active-set passes spent (team kernel), or null
     T *tAB;           // [B][Ns][TAB_ROWS] per-instance copy of (Ad rows | B rows | b) for the team kernel, or null
+    T *gbase;         // [Bp] growth certificate: max |B'PB| of the first factorisation of the solve (active-set kernel -> work-list launch), or null
     long long *prof;  // [8][Bp] per-sweep time stamps, NMPC_PROFILE builds only (else null)
 };
 

@@ -39,6 +39,8 @@ constexpr int AS_EV = 56;            // doubles per stage in the evaluation-poin
 constexpr int EV_T2 = 28, EV_B = 29, EV_RE = 42, EV_ZERO = 54;
 constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
+constexpr int IP_LM_ROWS = 88;       // ... of the kernels that also iterate the interior point method: | 1 / d_a of H_uu = L D L' (4) | pad
+constexpr int TLM_RINV = 52;         // the same four reciprocals in a stage's HBM row (52..63: the slot of the row form's L | m, unused here)
 // LDS carve per team, in doubles
 constexpr int A_AD = 0;              // [16][8]  rows of the dense A columns (natural layout)
 constexpr int A_B = A_AD + 128;      // [16][4]
@@ -83,10 +85,14 @@ struct WorkList {
     int *list;      // [Bp] instance indices
 };
 
-template <bool SHARED, bool TRAJ, bool LDSC, class TI>
+// MODE 0: preparation + the FIRST active-set attempt, give-ups to the work list (k_team_as: the first launch of the default path)
+// MODE 1: the whole QP for every instance of the batch - interior-point iterations, with the active-set attempts in between
+//         when qp_polish is on (k_team_qp: qp_polish = 0, an attempt schedule that does not start with an attempt, NMPC_TEAM_SPLIT=0)
+// MODE 2: the same for ONE chunk of the work list, continuing after a failed first attempt (k_team_qp_list: the second launch)
+template <bool SHARED, bool TRAJ, bool LDSC, class TI, int MODE = 0>
 __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
                                         const Outputs<TI> &out, const TeamWork<double> &tw, const WorkList &wl,
-                                        int B, int tpw, double *smem, int lds_stride, int lstg)
+                                        int B, int tpw, double *smem, int lds_stride, int lstg, int inst_ov = -2)
 {
     // lds_stride: doubles of LDS per team (carve below + the stage cache); lstg: the factors of stages 0 .. lstg-1 -
     // written last by the backward sweep and read first by the forward sweep - stay in LDS and never reach HBM
@@ -98,15 +104,16 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     using T = double;
     using NoPins = std::integral_constant<bool, false>;
     using WithPins = std::integral_constant<bool, true>;
-    constexpr int A_LM = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;      // stage cache: [lstg][AS_LM_ROWS]
+    constexpr int A_LM = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;      // stage cache: [lstg][LMR]
+    constexpr int LMR = MODE == 0 ? AS_LM_ROWS : IP_LM_ROWS;
     const int LDS_T = lds_stride;
     NMPC_PROF_BEGIN
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
     const int ta = r >> 2, tc = r & 3, j = tc;
     const int rr = r < NX ? r : NX - 1;
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = blockIdx.x * tpw + team;
-    const bool valid = team < tpw && inst < B;
+    int inst = MODE == 2 ? inst_ov : blockIdx.x * tpw + team;
+    const bool valid = MODE == 2 ? (inst >= 0 && inst < B) : (team < tpw && inst < B);
     if (!valid) inst = B - 1;             // idle teams read the inputs of the last instance ...
     const int winst = valid ? inst : w.Bp;   // ... and work in a spare workspace row, so that no store of a sweep is predicated
     const int lane = inst;                // profiling slot (NMPC_PROFILE builds)
@@ -297,385 +304,395 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     int status = 0, npol = 0, pass_in_attempt = 0;
     int k_top = N - 1;       // highest stage this team's next backward sweep has to refactorise
     int ck_valid = 0;        // checkpoints 1..ck_valid of this team are current
-    enum { M_POL = 1, M_DONE = 2, M_GIVEUP = 3 };
+    // per-team mode: active-set pass | finished | (MODE 0) handed to the work list | interior-point iteration | waiting for the
+    // wave's next active-set phase
+    enum { M_POL = 1, M_DONE = 2, M_GIVEUP = 3, M_IPM = 4, M_WAIT = 5 };
     int mode = valid ? M_POL : M_DONE;
     int pass = 0;            // wave-uniform pass counter: all live teams of a wave are in the same pass
+    bool nopins_pass = true; // wave-uniform: the pass starts from "all inputs free" (first pass of a first attempt)
     T u0_cand = 0;           // lane (a,0): candidate command of input a from the latest forward sweep
     // lanes of this team in a wave-wide ballot
     const unsigned long long team_mask = 0x000F000F000F000Full << (4 * team);
+    // state of the sweep in flight (set by the pass / iteration that runs it)
+    bool pol = false, pol2 = false, ok = true, nanp = false, viol = false, heavy = false;
+    int ks = N - 1, wnd = 0, kchgB = -1;
+    T xh = 0;
+    // growth certificate (nmpc_config.qp_growth_max): gm = max |B'PB| of the sweep in flight as this lane sees it, gbase = the
+    // team-wide value of the FIRST factorisation of the solve (0 = none yet)
+    T gm = 0, gbase = 0;
+    bool tripped = false;    // the certificate ended an attempt of this team: no further attempt is made
+    bool from_ua = MODE == 0; // the result is an accepted active-set solution (candidate inputs, xhat of its forward sweep)
+    // interior-point iteration (IPMK kernels): scalars of the corrector
+    T sigmu = 0;
+    using NoIpm = std::integral_constant<bool, false>;
+    using Ipm = std::integral_constant<bool, true>;
+    const T iw_a = T(1) / (ub_a - lb_a);          // step sizes are measured against the box width
 
-    for (;;) {
-        if (__ballot(mode == M_POL) == 0) break;
-        const bool pol = mode == M_POL;
-        tLM = pol ? tLM_own : tLM_spare; tIV = pol ? tIV_own : tIV_spare; tP = pol ? tP_own : tP_spare;
-        // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
-        int ks = N - 1;
-        if (tP && pass > 0) {
-            if (r == 0) { sRed[28] = (T)(pol ? k_top : -1); sRed[29] = (T)(pol ? ck_valid : N); }
-            __syncthreads();
-            ks = 0;
-            int vmin = N;            // every live team must own the checkpoint the wave resumes from
-            for (int t = 0; t < 4; t++) {
-                const int kt = (int)smem[t * LDS_T + A_RED + 28], vt = (int)smem[t * LDS_T + A_RED + 29];
-                ks = kt > ks ? kt : ks;
-                vmin = vt < vmin ? vt : vmin;
-            }
-            if (ks >= vmin) ks = N - 1;
-            ks = __builtin_amdgcn_readfirstlane(ks);
-        }
-        // checkpoint window of this pass (see team_ipm): two stages in the first pass, the configured window after
-        const int wnd = pass_in_attempt == 0 ? (ckpt < 2 ? ckpt : 2) : ckpt;
-        if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
-
-        // ================= sweep A: backward factorisation in tile form.
-        // Same products as the tile form of sweep A in team_ipm.  What differs is the shape of the code: a stage is
-        // ONE basic block (no predicated store: finished and idle teams work in a spare workspace row), P B and
-        // B'P B come first so that the 4x4 Cholesky - a serial chain of ~90
-        // vector instructions - runs beside the ~60 MFMAs that do not depend on it, and the first pass (nothing
-        // pinned, by construction) is compiled without any of the pin handling.
-        bool ok = true, nanp = false;
-        auto sweepA = [&](auto pins_tag) {
-            constexpr bool PINS = decltype(pins_tag)::value;
-            T Aq0[4], Aq1b[4], Bt[4];
-            auto load_tiles = [&]() {
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                    const int l = natR[kt] >= 0 ? natR[kt] : 0;
-                    const bool real = natR[kt] >= 0;
-                    const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc], bv_ = sbv[l];
-                    Aq0[kt] = real ? a0 : T(0);
-                    Aq1b[kt] = real ? (tc < 3 ? a1 : bv_) : ((kt == 3 && ta == 3 && tc == 3) ? T(1) : T(0));
-                    Bt[kt] = real ? bb : T(0);
-                }
-            };
-            if (SHARED) load_tiles(); else fetch_stage(ks, r);
-            T Pt[4][4];
-            if (ks == N - 1) {
-                // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
-                sh[r] = WqN_r * (xlin(N) - (T)ye[rr]);
-                NMPC_WSYNC();
-                NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                        T v = (it == jt && ta == tc && natR[it] >= 0) ? c.QdN[natR[it] >= 0 ? natR[it] : 0] : T(0);
-                        const T qa = sh[natR[it] >= 0 ? natR[it] : 0], qb = sh[natC[jt] >= 0 ? natC[jt] : 0];
-                        if (jt == 3 && tc == 3 && natR[it] >= 0) v = qa;
-                        if (it == 3 && ta == 3 && natC[jt] >= 0) v = qb;
-                        Pt[it][jt] = v;
-                    }
-                }
-                NMPC_WSYNC();
-            } else {                  // resume from the checkpoint an earlier pass left
-                const T *cp = tP + (size_t)(ks + 1) * TP_ROWS + r;
-                NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
-                }
-            }
-            // scalars of a stage are fetched one stage ahead (global loads stay in flight over the stage):
-            // reference row rr, reference / linearisation input of component j (pins) or a (no pins), pin code
-            const int cu = PINS ? j : ta;
-            T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + cu];
-            T n_xl = xlin(ks), n_ul = ulin(ks, cu);
-            T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
-            auto stage = [&](int k, auto last_tag, auto lds_tag) {
-                constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
-                constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
-                if (!SHARED) {
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
-                    if (!LAST) fetch_stage(k - 1, r);
-                }
-                T *lmk = tLM + k * TLM_ROWS;
-                const T ul = n_ul, pc = n_pc;
-                // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
-                // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
-                // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
-                // (found by the permutation test at N = 600)
-                T rk = (PINS ? Wr_j : Wr_a) * (ul - n_yu);
-                const T q_r = Wq_r * (n_xl - n_yx);
-                asm volatile("" : "+v"(rk));             // (q_r passes through LDS, which rounds it in both variants)
-                if (!LAST) {
-                    n_yx = (T)yr[(size_t)(k - 1) * NY + rr]; n_yu = (T)yr[(size_t)(k - 1) * NY + NX + cu];
-                    n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
-                    if (PINS) n_pc = tIV[(k - 1) * IV_ROWS + 16 + j];
-                }
-                T mask_a = T(1), mask_c = T(1), D_a = Rd_a, rhat_a = rk;
-                bool any_pins = false;
-                T Aq1[4];
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
-                if (!LAST) sh[r] = q_r;                  // natural row rr of the stage gradient
-                if (PINS) {
-                    // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps
-                    // R_jj so that u_j = bound
-                    const T lo = lbj - ul, hi = ubj - ul;
-                    const bool pinned = pol && pc != T(0);
-                    const T vpin = pc < T(0) ? lo : hi;
-                    if (cmpl) {
-                        sD[j] = Rdj;
-                        sD[4 + j] = pinned ? -Rdj * vpin : rk;
-                        sD[8 + j] = pinned ? T(0) : T(1);
-                        sD[12 + j] = pinned ? vpin : T(0);
-                    }
-                    NMPC_WSYNC();
-                    mask_a = sD[8 + ta]; mask_c = sD[8 + tc]; D_a = sD[ta]; rhat_a = sD[4 + ta];
-                    any_pins = __ballot(pinned) != 0;
-                    if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
-                        const T vp = sD[12 + tc];
-                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                            const T sm = quad_sum(Bt[kt] * vp);
-                            if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
-                        }
-                    }
-                }
-                // P B and Hr = B'PB first: the Cholesky below depends on nothing else
-                T WB[4], Hr = 0;
-                NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    T aB = 0;
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
-                    WB[it] = aB;
-                }
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
-                const T Huu = (PINS ? ((ta == tc) ? D_a : T(0)) : HuuD) + (PINS ? mask_a * mask_c * Hr : Hr);
-                if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
-                NMPC_WSYNC();
-                T Lf[10];
-                NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
-#if defined(NMPC_DEBUG_NAN) && defined(__HIP_DEVICE_COMPILE__) && defined(NMPC_PROFILE)
-                {   // diagnostic build (tools/dev/nan_probe.py): first stage at which a NaN reaches the factor stage, and where
-                    bool fa = false, fp = false, fh = false;
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) fa |= !(Aq0[t] == Aq0[t]) || !(Aq1[t] == Aq1[t]) || !(Bt[t] == Bt[t]);
-                    NMPC_UNROLL for (int a_ = 0; a_ < 4; a_++) { NMPC_UNROLL for (int b_ = 0; b_ < 4; b_++) fp |= !(Pt[a_][b_] == Pt[a_][b_]); }
-                    NMPC_UNROLL for (int i = 0; i < 10; i++) fh |= !(Lf[i] == Lf[i]);
-                    const int code = (__ballot(fa) & team_mask) ? 1 : ((__ballot(fp) & team_mask) ? 2 : ((__ballot(fh) & team_mask) ? 3 : 0));
-                    if (prof_acc_[5] == 0 && code) prof_acc_[5] = 1000000 + pass * 100000 + k * 100 + code;
-                }
-#endif
-                // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt)).  Tile (3,0) of Abar -
-                // d omega+ / d q and the homogeneous row - is identically zero (the body rates do not depend on the attitude):
-                // its products are left out here, in the (q,w) x (q,w) block below and in the forward sweep (94 MFMAs per stage)
-                T W0[4], W1[4];
-                NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    T a0 = 0, a1 = 0;
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                        if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
-                        a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
-                    }
-                    W0[it] = a0; W1[it] = a1;
-                }
-                T PA[4][4];
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                    PA[kt][0] = Pt[kt][0];
-                    PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
-                    PA[kt][2] = W0[kt];
-                    PA[kt][3] = W1[kt];
-                }
-                // X = B'(Pbar Abar) (column 15: B'h)
-                T X0raw = 0;
-                T X[4];
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                    T a = 0;
-                    if (jt == 0) a = mfma44(WB[0], Idt, T(0));
-                    else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
-                    else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
-                    if (jt == 0) X0raw = a;
-                    X[jt] = PINS ? mask_a * a : a;
-                    // gradient rows of the pinned inputs for the multiplier check of the forward sweep
-                    if (PINS) { if (any_pins) lmk[TLM_G + jt * 16 + tc * 4 + ta] = a; }
-                }
-                if (PINS) { if (any_pins) lmk[TLM_G + 64 + tc * 4 + ta] = Hr; }
-                if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
-                // the (q,w) x (q,w) tiles of Abar'(Pbar Abar) and the (p,v) rows: independent of the Cholesky
-                T Pn[4][4];
-                if (!LAST) {
-                    T qcol[4], qrow[4];       // column / row 15 of Qbar: the stage gradient, zero elsewhere (read from a zero slot)
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
-                    // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators: the ten tiles on and above
-                    // the diagonal only (see the update below)
-                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                        T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
-                        T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
-                        if (jt >= 2) {
-                            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                                if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                                if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
-                            }
-                        }
-                        Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
-                        Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
-                        Pn[2][jt] = a2;
-                        Pn[3][jt] = a3;
-                    }
-                }
-                // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
-                // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
-                // triangle needs 4 FMAs where the general one needed 16 operations, and FP64 vector instructions are paid
-                // in full here - they share the SIMD's double-precision pipe with the MFMAs.
-                // c_ij = l_ij d_j are the unscaled column entries.
-                T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
-                {
-                    const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
-                    const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
-                    auto pivot = [&](T d) -> T {
-                        const bool pos = d > T(0);
-                        ok &= pos; nanp |= !(d == d);
-                        return fast_rcp(pos ? d : T(1));
-                    };
-                    r0 = pivot(h00);
-                    l10 = h10 * r0; l20 = h20 * r0; l30 = h30 * r0;
-                    r1 = pivot(h11 - l10 * h10);
-                    const T c21 = h21 - l20 * h10, c31 = h31 - l30 * h10;
-                    l21 = c21 * r1; l31 = c31 * r1;
-                    r2 = pivot(h22 - l20 * h20 - l21 * c21);
-                    const T c32 = h32 - l30 * h20 - l31 * c21;
-                    l32 = c32 * r2;
-                    r3 = pivot(h33 - l30 * h30 - l31 * c31 - l32 * c32);
-                }
-                // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the unit triangle in closed form and
-                // one select by the lane's (c,a): straight-line code - a forward substitution on the unit vector e_a, as
-                // the general kernel does it, compiles to lane-divergent branches that cut the stage's scheduling region
-                T Y;
-                {
-                    const T i10 = -l10, i21 = -l21, i32 = -l32;
-                    const T i20 = -(l20 + l21 * i10);
-                    const T i31 = -(l31 + l32 * i21);
-                    const T i30 = -(l30 + l31 * i10 + l32 * i20);
-                    const int e = tc * 4 + ta;           // (row c, column a) of L^-1
-                    Y = (ta == tc) ? T(1) : T(0);
-                    Y = e == 4 ? i10 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
-                    Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y;
-                }
-                // M0 = L^-1 X, M = D^-1 M0 (row a of the tile by 1 / d_a): the feedback is u = -L^-T (M xbar), the Riccati
-                // update subtracts M0' M
-                const T ra = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : r3));
-                T M0[4], M[4];
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                    M0[jt] = mfma44(Y, X[jt], T(0));
-                    M[jt] = ra * M0[jt];
-                    // stored where the forward sweep reads it transposed
-                    if (LDSST) sLM[k * AS_LM_ROWS + jt * 16 + tc * 4 + ta] = M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
-                }
-                const T Zt = mfma44(Y, Idt, T(0));                            // Y' = L^-1 as a tile
-                if (LDSST) sLM[k * AS_LM_ROWS + 64 + r] = Zt; else lmk[TLM_Z + r] = Zt;
-                if (!LAST) {
-                    T Mn[4];
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
-                    // Pbar is kept EXACTLY symmetric: products for the tiles on and above the diagonal, the diagonal tiles
-                    // averaged with their transposes, the tiles below as transposes (X' I transposes a tile).  Computed
-                    // independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
-                    // contracted by the recursion: it grows by rho(A)^2 per stage - harmless for the reference's vehicle
-                    // (rho = 1.04), a NaN after ~30 stages where the discretised open loop is violently unstable (dt = 0.1 with
-                    // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The row form, the
-                    // lane kernel and the oracle carry one triangle of P only.
-                    NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
-                    }
-                    NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
-                    NMPC_UNROLL for (int it = 1; it < 4; it++) {
-                        NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
-                    }
-                    if (tP && k <= wnd) {
-                        T *cp = tP + (size_t)k * TP_ROWS + r;
-                        NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
-                        }
-                    }
-                }
-                NMPC_WSYNC();
-            };
-            using Fl = std::integral_constant<bool, false>;
-            using Tr = std::integral_constant<bool, true>;
-            int k = ks;
-            if constexpr (LDSC) {
-                const int kg = lstg > 1 ? lstg : 1;
-                for (; k >= kg; k--) stage(k, Fl{}, Fl{});        // factors to HBM
-                for (; k > 0; k--) stage(k, Fl{}, Tr{});          // factors stay in LDS
-                if (lstg > 0) stage(0, Tr{}, Tr{}); else stage(0, Tr{}, Fl{});
-            } else {
-                for (; k > 0; k--) stage(k, Fl{}, Fl{});
-                stage(0, Tr{}, Fl{});
+    // ================= sweep A: backward factorisation in tile form.
+    // Same products as the tile form of sweep A in team_ipm.  What differs is the shape of the code: a stage is
+    // ONE basic block (no predicated store: finished and idle teams work in a spare workspace row), P B and
+    // B'P B come first so that the 4x4 Cholesky - a serial chain of ~90
+    // vector instructions - runs beside the ~60 MFMAs that do not depend on it, and the first pass (nothing
+    // pinned, by construction) is compiled without any of the pin handling.
+    auto sweepA = [&](auto pins_tag, auto ipm_tag) {
+        constexpr bool PINS = decltype(pins_tag)::value;
+        constexpr bool IPMV = decltype(ipm_tag)::value;     // interior-point iteration: barrier terms on the input Hessian, nothing pinned
+        T Aq0[4], Aq1b[4], Bt[4];
+        auto load_tiles = [&]() {
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                const int l = natR[kt] >= 0 ? natR[kt] : 0;
+                const bool real = natR[kt] >= 0;
+                const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc], bv_ = sbv[l];
+                Aq0[kt] = real ? a0 : T(0);
+                Aq1b[kt] = real ? (tc < 3 ? a1 : bv_) : ((kt == 3 && ta == 3 && tc == 3) ? T(1) : T(0));
+                Bt[kt] = real ? bb : T(0);
             }
         };
-        if (pass == 0) sweepA(NoPins{}); else sweepA(WithPins{});
-        NMPC_STAMP(0)
-        __syncthreads();
-        bool pol_fail = false;
-        if (pol && !ok) {
-            // A NaN pivot with nothing pinned (first pass) means NaN data: status 1.  In a later pass it can be the pinned
-            // recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per
-            // stage there - and is one more way for the attempt to fail: the interior point iteration takes over, as in the
-            // oracle (ocpqp_polish breaks out of a pass that produced a NaN)
-            if (nanp && pass == 0) { status = 1; mode = M_DONE; }
-            else pol_fail = true;                       // give up this attempt
+        if (SHARED) load_tiles(); else fetch_stage(ks, r);
+        T Pt[4][4];
+        if (ks == N - 1) {
+            // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
+            sh[r] = WqN_r * (xlin(N) - (T)ye[rr]);
+            NMPC_WSYNC();
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    T v = (it == jt && ta == tc && natR[it] >= 0) ? c.QdN[natR[it] >= 0 ? natR[it] : 0] : T(0);
+                    const T qa = sh[natR[it] >= 0 ? natR[it] : 0], qb = sh[natC[jt] >= 0 ? natC[jt] : 0];
+                    if (jt == 3 && tc == 3 && natR[it] >= 0) v = qa;
+                    if (it == 3 && ta == 3 && natC[jt] >= 0) v = qb;
+                    Pt[it][jt] = v;
+                }
+            }
+            NMPC_WSYNC();
+        } else {                  // resume from the checkpoint an earlier pass left
+            const T *cp = tP + (size_t)(ks + 1) * TP_ROWS + r;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = cp[(it * 4 + jt) * 16];
+            }
         }
-        const bool pol2 = mode == M_POL;
-
-        // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
-        // is one basic block; operands arrive two stages ahead in two alternating register sets
-        bool viol = false, heavy = false;
-        int kchgB = -1;           // highest stage whose pin set this pass changes
-        T xh = 0;
-        auto sweepB = [&](auto pins_tag) {
-            constexpr bool PINS = decltype(pins_tag)::value;
-            T AT2[4], AT3[4], BT[4];
-            auto load_tiles_T = [&]() {
+        // scalars of a stage are fetched one stage ahead (global loads stay in flight over the stage):
+        // reference row rr, reference / linearisation input of component j (pins) or a (no pins), pin code
+        const int cu = PINS ? j : ta;
+        T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + cu];
+        T n_xl = xlin(ks), n_ul = ulin(ks, cu);
+        T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
+        T n_u = 0, n_ll = 0, n_lu = 0;                       // the iterate of input a (interior-point variant)
+        if (IPMV) { n_u = tIV[ks * IV_ROWS + ta]; n_ll = tIV[ks * IV_ROWS + 4 + ta]; n_lu = tIV[ks * IV_ROWS + 8 + ta]; }
+        auto stage = [&](int k, auto last_tag, auto lds_tag) {
+            constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
+            constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
+            if (!SHARED) {
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
+                if (!LAST) fetch_stage(k - 1, r);
+            }
+            T *lmk = tLM + k * TLM_ROWS;
+            const T ul = n_ul, pc = n_pc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
+            // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
+            // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
+            // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
+            // (found by the permutation test at N = 600)
+            T rk = (PINS ? Wr_j : Wr_a) * (ul - n_yu);
+            const T q_r = Wq_r * (n_xl - n_yx);
+            asm volatile("" : "+v"(rk));             // (q_r passes through LDS, which rounds it in both variants)
+            if (!LAST) {
+                n_yx = (T)yr[(size_t)(k - 1) * NY + rr]; n_yu = (T)yr[(size_t)(k - 1) * NY + NX + cu];
+                n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
+                if (PINS) n_pc = tIV[(k - 1) * IV_ROWS + 16 + j];
+                if (IPMV) { const T *ivn = tIV + (k - 1) * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
+            }
+            T mask_a = T(1), mask_c = T(1), D_a = Rd_a, rhat_a = rk;
+            if (IPMV) {
+                // barrier terms of the interior-point iteration: D = R + lam_l / t_l + lam_u / t_u, rhat = r - (D - R) u
+                const Pair<T> pr(u_it, ll_it, lu_it, lb_a - ul, ub_a - ul);
+                const T sg = pr.kl + pr.ku;
+                D_a = Rd_a + sg;
+                rhat_a = rk - sg * u_it;
+            }
+            bool any_pins = false;
+            T Aq1[4];
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
+            if (!LAST) sh[r] = q_r;                  // natural row rr of the stage gradient
+            if (PINS) {
+                // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps
+                // R_jj so that u_j = bound
+                const T lo = lbj - ul, hi = ubj - ul;
+                const bool pinned = pol && pc != T(0);
+                const T vpin = pc < T(0) ? lo : hi;
+                if (cmpl) {
+                    sD[j] = Rdj;
+                    sD[4 + j] = pinned ? -Rdj * vpin : rk;
+                    sD[8 + j] = pinned ? T(0) : T(1);
+                    sD[12 + j] = pinned ? vpin : T(0);
+                }
+                NMPC_WSYNC();
+                mask_a = sD[8 + ta]; mask_c = sD[8 + tc]; D_a = sD[ta]; rhat_a = sD[4 + ta];
+                any_pins = __ballot(pinned) != 0;
+                if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
+                    const T vp = sD[12 + tc];
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                        const T sm = quad_sum(Bt[kt] * vp);
+                        if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
+                    }
+                }
+            }
+            // P B and Hr = B'PB first: the Cholesky below depends on nothing else
+            T WB[4], Hr = 0;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                T aB = 0;
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
+                WB[it] = aB;
+            }
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
+            const T Hrm = PINS ? mask_a * mask_c * Hr : Hr;
+            gm = fmax(gm, fabs(Hrm));                    // growth certificate: max |B'PB| as the free inputs see it
+            const T Huu = ((PINS || IPMV) ? ((ta == tc) ? D_a : T(0)) : HuuD) + Hrm;
+            if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
+            NMPC_WSYNC();
+            T Lf[10];
+            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
+#if defined(NMPC_DEBUG_NAN) && defined(__HIP_DEVICE_COMPILE__) && defined(NMPC_PROFILE)
+            {   // diagnostic build (tools/dev/nan_probe.py): first stage at which a NaN reaches the factor stage, and where
+                bool fa = false, fp = false, fh = false;
+                NMPC_UNROLL for (int t = 0; t < 4; t++) fa |= !(Aq0[t] == Aq0[t]) || !(Aq1[t] == Aq1[t]) || !(Bt[t] == Bt[t]);
+                NMPC_UNROLL for (int a_ = 0; a_ < 4; a_++) { NMPC_UNROLL for (int b_ = 0; b_ < 4; b_++) fp |= !(Pt[a_][b_] == Pt[a_][b_]); }
+                NMPC_UNROLL for (int i = 0; i < 10; i++) fh |= !(Lf[i] == Lf[i]);
+                const int code = (__ballot(fa) & team_mask) ? 1 : ((__ballot(fp) & team_mask) ? 2 : ((__ballot(fh) & team_mask) ? 3 : 0));
+                if (prof_acc_[5] == 0 && code) prof_acc_[5] = 1000000 + pass * 100000 + k * 100 + code;
+            }
+#endif
+            // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt)).  Tile (3,0) of Abar -
+            // d omega+ / d q and the homogeneous row - is identically zero (the body rates do not depend on the attitude):
+            // its products are left out here, in the (q,w) x (q,w) block below and in the forward sweep (94 MFMAs per stage)
+            T W0[4], W1[4];
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                T a0 = 0, a1 = 0;
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                    a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
+                }
+                W0[it] = a0; W1[it] = a1;
+            }
+            T PA[4][4];
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                PA[kt][0] = Pt[kt][0];
+                PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
+                PA[kt][2] = W0[kt];
+                PA[kt][3] = W1[kt];
+            }
+            // X = B'(Pbar Abar) (column 15: B'h)
+            T X0raw = 0;
+            T X[4];
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                T a = 0;
+                if (jt == 0) a = mfma44(WB[0], Idt, T(0));
+                else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
+                else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
+                if (jt == 0) X0raw = a;
+                X[jt] = PINS ? mask_a * a : a;
+                // gradient rows of the pinned inputs for the multiplier check of the forward sweep
+                if (PINS) { if (any_pins) lmk[TLM_G + jt * 16 + tc * 4 + ta] = a; }
+            }
+            if (PINS) { if (any_pins) lmk[TLM_G + 64 + tc * 4 + ta] = Hr; }
+            if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
+            // the (q,w) x (q,w) tiles of Abar'(Pbar Abar) and the (p,v) rows: independent of the Cholesky
+            T Pn[4][4];
+            if (!LAST) {
+                T qcol[4], qrow[4];       // column / row 15 of Qbar: the stage gradient, zero elsewhere (read from a zero slot)
+                NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
+                // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators: the ten tiles on and above
+                // the diagonal only (see the update below)
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                    T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
+                    T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
+                    if (jt >= 2) {
+                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                            if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                            if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                        }
+                    }
+                    Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
+                    Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
+                    Pn[2][jt] = a2;
+                    Pn[3][jt] = a3;
+                }
+            }
+            // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
+            // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
+            // triangle needs 4 FMAs where the general one needed 16 operations, and FP64 vector instructions are paid
+            // in full here - they share the SIMD's double-precision pipe with the MFMAs.
+            // c_ij = l_ij d_j are the unscaled column entries.
+            T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
+            {
+                const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
+                const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
+                auto pivot = [&](T d) -> T {
+                    const bool pos = d > T(0);
+                    ok &= pos; nanp |= !(d == d);
+                    return fast_rcp(pos ? d : T(1));
+                };
+                r0 = pivot(h00);
+                l10 = h10 * r0; l20 = h20 * r0; l30 = h30 * r0;
+                r1 = pivot(h11 - l10 * h10);
+                const T c21 = h21 - l20 * h10, c31 = h31 - l30 * h10;
+                l21 = c21 * r1; l31 = c31 * r1;
+                r2 = pivot(h22 - l20 * h20 - l21 * c21);
+                const T c32 = h32 - l30 * h20 - l31 * c21;
+                l32 = c32 * r2;
+                r3 = pivot(h33 - l30 * h30 - l31 * c31 - l32 * c32);
+            }
+            // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the unit triangle in closed form and
+            // one select by the lane's (c,a): straight-line code - a forward substitution on the unit vector e_a, as
+            // the general kernel does it, compiles to lane-divergent branches that cut the stage's scheduling region
+            T Y;
+            {
+                const T i10 = -l10, i21 = -l21, i32 = -l32;
+                const T i20 = -(l20 + l21 * i10);
+                const T i31 = -(l31 + l32 * i21);
+                const T i30 = -(l30 + l31 * i10 + l32 * i20);
+                const int e = tc * 4 + ta;           // (row c, column a) of L^-1
+                Y = (ta == tc) ? T(1) : T(0);
+                Y = e == 4 ? i10 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
+                Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y;
+            }
+            // M0 = L^-1 X, M = D^-1 M0 (row a of the tile by 1 / d_a): the feedback is u = -L^-T (M xbar), the Riccati
+            // update subtracts M0' M
+            const T ra = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : r3));
+            T M0[4], M[4];
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                M0[jt] = mfma44(Y, X[jt], T(0));
+                M[jt] = ra * M0[jt];
+                // stored where the forward sweep reads it transposed
+                if (LDSST) sLM[k * LMR + jt * 16 + tc * 4 + ta] = M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
+            }
+            const T Zt = mfma44(Y, Idt, T(0));                            // Y' = L^-1 as a tile
+            if (LDSST) sLM[k * LMR + 64 + r] = Zt; else lmk[TLM_Z + r] = Zt;
+            if (IPMV) {              // 1 / d_a for the corrector's solves (lanes (a, c != 0) store the same value to a spare slot)
+                const int rs = ta + (tc == 0 ? 0 : 4);
+                if (LDSST) sLM[k * LMR + 80 + rs] = ra; else lmk[TLM_RINV + rs] = ra;
+            }
+            if (!LAST) {
+                T Mn[4];
+                NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
+                // Pbar is kept EXACTLY symmetric: products for the tiles on and above the diagonal, the diagonal tiles
+                // averaged with their transposes, the tiles below as transposes (X' I transposes a tile).  Computed
+                // independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
+                // contracted by the recursion: it grows by rho(A)^2 per stage - harmless for the reference's vehicle
+                // (rho = 1.04), a NaN after ~30 stages where the discretised open loop is violently unstable (dt = 0.1 with
+                // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The row form, the
+                // lane kernel and the oracle carry one triangle of P only.
                 NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    const int l = natC[it] >= 0 ? natC[it] : 0;
-                    const bool real = natC[it] >= 0;
-                    const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta], bv_ = sbv[l];
-                    AT2[it] = real ? a2 : T(0);
-                    AT3[it] = real ? (ta < 3 ? a3 : bv_) : ((it == 3 && tc == 3 && ta == 3) ? T(1) : T(0));
-                    BT[it] = real ? bb : T(0);
+                    NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
                 }
-            };
-            if (SHARED) load_tiles_T();
-            T xt[4];
-            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
-            // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
-            int xslot[4];
-            NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
-            const int cslot = tc == 0 ? 12 + ta : 0, pslot = tc == 0 ? 16 + ta : 0;
-            struct Ops { T mt[4], z, ul, pc, ab[SHARED ? 1 : 12]; };
-            const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // factors of stages [0, kl) come from LDS, [kl, N) from HBM
-            // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon).  Per-stage
-            // linearisation: the stage tiles (transposed) travel with them - two to four stages ahead, where one stage
-            // ahead left the 0.33 us stage waiting on a 1 us load - and the loop below covers the LDS-cached stages too
-            auto fetch_ops = [&](int kq, Ops &o) {
-                const int k = kq < N ? kq : N - 1;   // clamped, NOT skipped: a branch around the loads makes the compiler's
-                                                     // wait-count model assume the fewest loads in flight, and every stage
-                                                     // then waits for the prefetch issued just before it
-                const T *lmn = tLM + k * TLM_ROWS;
-                if (SHARED || k >= kl) {
-                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
-                    o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+                NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
+                NMPC_UNROLL for (int it = 1; it < 4; it++) {
+                    NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
                 }
-                o.ul = ulin(k, ta);
-                o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
-                if (!SHARED) {
-                    const T *a = tAB + (size_t)k * TAB_ROWS + rT;
-                    NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
+                if (!IPMV && tP && k <= wnd) {
+                    T *cp = tP + (size_t)k * TP_ROWS + r;
+                    NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
+                    }
                 }
-            };
-            // ... and from the LDS stage cache (scalars still come from global memory, one stage ahead)
-            auto fetch_ops_lds = [&](int k, Ops &o) {
-                const T *lmn = sLM + k * AS_LM_ROWS;
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[jt * 16 + r];
-                o.z = lmn[64 + r];
-            };
-            auto stageB = [&](int k, Ops &o) {
-                if (!SHARED) {
-                    NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = o.ab[it * 3]; AT3[it] = o.ab[it * 3 + 1]; BT[it] = o.ab[it * 3 + 2]; }
-                    if (LDSC) { if (k < kl) fetch_ops_lds(k, o); }
-                }
-                T *ivk = tIV + k * IV_ROWS;
-                const T ul = o.ul, pc = o.pc;
-                if (TRAJ) {                    // xhat_k for the output sweep
-                    T *xs = tLM + k * TLM_ROWS + 66;
-                    NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
-                }
-                T xn[4];
-                xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
-                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);   // tile (3,0) of Abar is zero
-                const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
-                          + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
-                const T ut = -mfma44(o.z, v, T(0));                           // lane (a,0): u_a
-                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+            }
+            NMPC_WSYNC();
+        };
+        using Fl = std::integral_constant<bool, false>;
+        using Tr = std::integral_constant<bool, true>;
+        int k = ks;
+        if constexpr (LDSC) {
+            const int kg = lstg > 1 ? lstg : 1;
+            for (; k >= kg; k--) stage(k, Fl{}, Fl{});        // factors to HBM
+            for (; k > 0; k--) stage(k, Fl{}, Tr{});          // factors stay in LDS
+            if (lstg > 0) stage(0, Tr{}, Tr{}); else stage(0, Tr{}, Fl{});
+        } else {
+            for (; k > 0; k--) stage(k, Fl{}, Fl{});
+            stage(0, Tr{}, Fl{});
+        }
+    };
+    // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
+    // is one basic block; operands arrive two stages ahead in two alternating register sets
+    auto sweepB = [&](auto pins_tag, auto ipm_tag) {
+        constexpr bool PINS = decltype(pins_tag)::value;
+        constexpr bool IPMV = decltype(ipm_tag)::value;     // predictor of an interior-point iteration: affine target, step length terms
+        T rmaxB = T(1), s2B = 0;                            // largest inverse step length (floor 1), complementarity of the affine step
+        T AT2[4], AT3[4], BT[4];
+        auto load_tiles_T = [&]() {
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                const int l = natC[it] >= 0 ? natC[it] : 0;
+                const bool real = natC[it] >= 0;
+                const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta], bv_ = sbv[l];
+                AT2[it] = real ? a2 : T(0);
+                AT3[it] = real ? (ta < 3 ? a3 : bv_) : ((it == 3 && tc == 3 && ta == 3) ? T(1) : T(0));
+                BT[it] = real ? bb : T(0);
+            }
+        };
+        if (SHARED) load_tiles_T();
+        T xt[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+        // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
+        int xslot[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
+        const int cslot = tc == 0 ? 12 + ta : 20 + ta, pslot = tc == 0 ? 16 + ta : 20 + ta;
+        struct Ops { T mt[4], z, ul, pc, u, ll, lu, ab[SHARED ? 1 : 12]; };
+        const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // factors of stages [0, kl) come from LDS, [kl, N) from HBM
+        // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon).  Per-stage
+        // linearisation: the stage tiles (transposed) travel with them - two to four stages ahead, where one stage
+        // ahead left the 0.33 us stage waiting on a 1 us load - and the loop below covers the LDS-cached stages too
+        auto fetch_ops = [&](int kq, Ops &o) {
+            const int k = kq < N ? kq : N - 1;   // clamped, NOT skipped: a branch around the loads makes the compiler's
+                                                 // wait-count model assume the fewest loads in flight, and every stage
+                                                 // then waits for the prefetch issued just before it
+            const T *lmn = tLM + k * TLM_ROWS;
+            if (SHARED || k >= kl) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];   // Mbar[c][4jt+a]
+                o.z = lmn[TLM_Z + r];                                                            // (L^-1)[a][c]
+            }
+            o.ul = ulin(k, ta);
+            o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
+            if (IPMV) { const T *ivn = tIV + k * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; }
+            if (!SHARED) {
+                const T *a = tAB + (size_t)k * TAB_ROWS + rT;
+                NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
+            }
+        };
+        // ... and from the LDS stage cache (scalars still come from global memory, one stage ahead)
+        auto fetch_ops_lds = [&](int k, Ops &o) {
+            const T *lmn = sLM + k * LMR;
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[jt * 16 + r];
+            o.z = lmn[64 + r];
+        };
+        auto stageB = [&](int k, Ops &o) {
+            if (!SHARED) {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = o.ab[it * 3]; AT3[it] = o.ab[it * 3 + 1]; BT[it] = o.ab[it * 3 + 2]; }
+                if (LDSC) { if (k < kl) fetch_ops_lds(k, o); }
+            }
+            T *ivk = tIV + k * IV_ROWS;
+            const T ul = o.ul, pc = o.pc;
+            if (TRAJ && !IPMV) {           // xhat_k for the output sweep
+                T *xs = tLM + k * TLM_ROWS + 66;
+                NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
+            }
+            T xn[4];
+            xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);   // tile (3,0) of Abar is zero
+            const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
+                      + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
+            const T ut = -mfma44(o.z, v, T(0));                           // lane (a,0): u_a
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+            if constexpr (IPMV) {
+                // affine-scaling target of input a in lane (a,0): step-length terms of the predictor, target kept for the corrector
+                const T uj = ut;
+                const T lo = lb_a - ul, hi = ub_a - ul;
+                const Pair<T> pr(o.u, o.ll, o.lu, lo, hi);
+                const T d = uj - o.u;
+                const T dla = -o.ll - pr.kl * d, dua = -o.lu + pr.ku * d;
+                // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
+                const T a1 = d * pr.itl, a2 = d * pr.itu;
+                rmaxB = fmax(rmaxB, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
+                s2B += dla * d - dua * d;
+                ivk[cslot] = uj;
+                (void)pc;
+            } else {
                 // KKT check of the pass, input a in lane (a,0): a free input must sit inside its box; a pinned one
                 // must have a multiplier of the right sign (gradient from the rows the factor sweep left)
                 const T uj = ut;
@@ -711,48 +728,404 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 heavy |= nanq;
                 viol |= npc != pc;
                 kchgB = (npc != pc) ? k : kchgB;                               // ascending k: the last one is the highest
-                NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
-            };
-            // Stages in flight: two sets of H = 2.  (The stage sits on its dependent MFMA chain - 0.3 us whether the operands
-            // come from LDS or from HBM; 2 x 3 and 2 x 4 stages in flight, also issued ahead of the LDS phase, measured the
-            // same 61-63 M solves/s.)
-            constexpr int H = 2;
-            constexpr bool PRE = false;
-            Ops oa[H], ob[H];
-            const int kb = SHARED ? kl : 0;                      // first stage of the main loop
-            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + i, oa[i]);
-            if (PRE) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + H + i, ob[i]); }
-            if constexpr (LDSC && SHARED) {
-                if (kl > 0) {
-                    Ops ol;
-                    T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
-                    fetch_ops_lds(0, ol);
-                    for (int k = 0; k < kl; k++) {
-                        ol.ul = n_ul; ol.pc = n_pc;
-                        const int kn = k + 1 < N ? k + 1 : k;
-                        n_ul = ulin(kn, ta);
-                        if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
-                        stageB(k, ol);
-                        if (k + 1 < kl) fetch_ops_lds(k + 1, ol);
-                    }
+            }
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
+        };
+        // Stages in flight: two sets of H = 2.  (The stage sits on its dependent MFMA chain - 0.3 us whether the operands
+        // come from LDS or from HBM; 2 x 3 and 2 x 4 stages in flight, also issued ahead of the LDS phase, measured the
+        // same 61-63 M solves/s.)
+        constexpr int H = 2;
+        constexpr bool PRE = false;
+        Ops oa[H], ob[H];
+        const int kb = SHARED ? kl : 0;                      // first stage of the main loop
+        NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + i, oa[i]);
+        if (PRE) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + H + i, ob[i]); }
+        if constexpr (LDSC && SHARED) {
+            if (kl > 0) {
+                Ops ol;
+                T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
+                T n_u = 0, n_ll = 0, n_lu = 0;
+                if (IPMV) { n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta]; }
+                fetch_ops_lds(0, ol);
+                for (int k = 0; k < kl; k++) {
+                    ol.ul = n_ul; ol.pc = n_pc; ol.u = n_u; ol.ll = n_ll; ol.lu = n_lu;
+                    const int kn = k + 1 < N ? k + 1 : k;
+                    n_ul = ulin(kn, ta);
+                    if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
+                    if (IPMV) { const T *ivn = tIV + kn * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
+                    stageB(k, ol);
+                    if (k + 1 < kl) fetch_ops_lds(k + 1, ol);
                 }
             }
-            for (int k0 = kb; k0 < N; k0 += 2 * H) {
-                if (!PRE || k0 != kb) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + H + i, ob[i]); }
-                NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + i < N) stageB(k0 + i, oa[i]); }
-                NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + 2 * H + i, oa[i]);
-                NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + H + i < N) stageB(k0 + H + i, ob[i]); }
+        }
+        for (int k0 = kb; k0 < N; k0 += 2 * H) {
+            if (!PRE || k0 != kb) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + H + i, ob[i]); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + i < N) stageB(k0 + i, oa[i]); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + 2 * H + i, oa[i]);
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + H + i < N) stageB(k0 + H + i, ob[i]); }
+        }
+        // back to one natural row per lane
+        if (tc == 0) {
+            NMPC_UNROLL for (int t = 0; t < 4; t++)
+                if (natR[t] >= 0) sXh[natR[t]] = xt[t];
+        }
+        NMPC_WSYNC();
+        xh = sXh[rr];
+        if (tc == 0) sRed[28 + ta] = (T)kchgB;
+        if (IPMV) { if (tc == 0) { sRed[4 + ta] = rmaxB; sRed[8 + ta] = s2B; } }
+    };
+    // ================= interior-point iteration (kernels of MODE 1 / 2 only; generic lambdas: never instantiated in MODE 0).
+    // Same sweeps as the tile form of team_ipm (nmpc_team.hpp) in the shape of this file: a stage is one basic block, idle
+    // and finished teams work in the spare workspace row, factors of the leading stages come from the LDS stage cache.
+    // H_uu = L D L' here (unit L): the factor sweep leaves Mbar = D^-1 L^-1 X, L^-1 and the four 1 / d_a; with m0 = L^-1 g the
+    // corrector's costate is pi_k = Abar' pi - Mbar' m0 and its feed-forward term is m = D^-1 m0 (column 15 of Mbar).
+    //
+    // start point of the iteration (HPIPM-style cold start, oracle ocpqp_ipm): inputs pushed inside the box, lam = mu0 / slack
+    auto init_point = [&](bool mine) {
+        constexpr int CHI = 10;
+        for (int k0 = 0; k0 < N; k0 += CHI) {
+            T ulv[CHI];
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) ulv[i] = ulin((k0 + i < N) ? k0 + i : N - 1, ta);
+            NMPC_UNROLL for (int i = 0; i < CHI; i++) {
+                const int k = k0 + i;
+                const T lo = lb_a - ulv[i], hi = ub_a - ulv[i];
+                T thr = c.thr0;
+                if (c.thr0_rel * (hi - lo) > thr) thr = c.thr0_rel * (hi - lo);
+                if (hi - lo < T(2) * thr) thr = T(0.5) * (hi - lo);
+                T v = 0;
+                if (v - lo < thr) v = lo + thr;
+                if (hi - v < thr) v = hi - thr;
+                if (k < N && tc == 0 && mine) {
+                    T *ivk = tIV_own + k * IV_ROWS;
+                    ivk[ta] = v;
+                    ivk[4 + ta] = c.mu0 / (v - lo);
+                    ivk[8 + ta] = c.mu0 / (hi - v);
+                }
             }
-            // back to one natural row per lane
-            if (tc == 0) {
-                NMPC_UNROLL for (int t = 0; t < 4; t++)
-                    if (natR[t] >= 0) sXh[natR[t]] = xt[t];
+        }
+    };
+    T rmaxE = 0, dmaxE = 0;        // sweep E: largest inverse step length (floor tau), largest |d| / box width
+    struct OpsD { T mn[4], y, ri, u, ll, lu, ua, ul; };
+    // ================= sweep D: backward homogeneous solve of the corrector: g = dr + B'pi, m0 = L^-1 g, pi_k = Abar'pi - Mbar'm0
+    auto sweepD = [&](auto) {
+        T Aq0[4], Aq1z[4], Bt[4];
+        if (SHARED) {            // as the factor sweep's tiles, without b and the homogeneous 1
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                const int l = natR[kt] >= 0 ? natR[kt] : 0;
+                const bool real = natR[kt] >= 0;
+                const T a0 = sAd[l * 8 + tc], a1 = sAd[l * 8 + 4 + (tc < 3 ? tc : 0)], bb = sB[l * 4 + tc];
+                Aq0[kt] = real ? a0 : T(0);
+                Aq1z[kt] = (real && tc < 3) ? a1 : T(0);
+                Bt[kt] = real ? bb : T(0);
             }
-            NMPC_WSYNC();
-            xh = sXh[rr];
-            if (tc == 0) sRed[28 + ta] = (T)kchgB;
+        } else fetch_stage(N - 1, r);
+        T pit[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) pit[t] = 0;
+        const int kl = LDSC ? (lstg < N ? lstg : N) : 0;
+        auto fetch_sc = [&](int kq, OpsD &o) {
+            const int k = kq > 0 ? kq : 0;
+            const T *ivn = tIV + k * IV_ROWS;
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
         };
-        if (pass == 0) sweepB(NoPins{}); else sweepB(WithPins{});
+        auto fetch_d = [&](int kq, OpsD &o) {           // factors from the HBM scratch (clamped index, see sweep B)
+            const int k = kq > 0 ? kq : 0;
+            const T *lmn = tLM + k * TLM_ROWS;
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mn[jt] = lmn[TLM_MT + jt * 16 + rT];     // Mbar[a][4jt+c]
+            o.y = lmn[TLM_Z + rT];                                                             // (L^-1)[c][a]
+            o.ri = lmn[TLM_RINV + ta];
+            fetch_sc(kq, o);
+        };
+        auto fetch_d_lds = [&](int k, OpsD &o) {
+            const T *lmn = sLM + k * LMR;
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mn[jt] = lmn[jt * 16 + rT];
+            o.y = lmn[64 + rT];
+            o.ri = lmn[80 + ta];
+        };
+        auto stageD = [&](int k, OpsD &o, auto lds_tag) {
+            constexpr bool LDSST = decltype(lds_tag)::value;
+            if (!SHARED) {
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1z[kt] = tc < 3 ? pfs[kt * 3 + 1] : T(0); Bt[kt] = pfs[kt * 3 + 2]; }
+                if (k > 0) fetch_stage(k - 1, r);
+            }
+            T drt;
+            {
+                const Pair<T> pr(o.u, o.ll, o.lu, lb_a - o.ul, ub_a - o.ul);
+                const T da = o.ua - o.u;
+                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
+                drt = tc == 0 ? -(sigmu - cl) * pr.itl + (sigmu - cu) * pr.itu : T(0);
+            }
+            const T g = mfma44(Bt[2], pit[2], mfma44(Bt[0], pit[0], drt)) + mfma44(Bt[3], pit[3], mfma44(Bt[1], pit[1], T(0)));
+            const T m0 = mfma44(o.y, g, T(0));                        // lane (a,0): (L^-1 g)_a
+            const T mst = o.ri * m0;
+            if (LDSST) sLM[k * LMR + (tc == 0 ? 60 + ta : 84 + ta)] = mst;
+            else tLM[k * TLM_ROWS + (tc == 0 ? TLM_MT + 60 + ta : TLM_RINV + 4 + ta)] = mst;
+            if (k > 0) {
+                T an[4];
+                an[0] = pit[0];
+                an[1] = dt_v * pit[0] + pit[1];
+                an[2] = mfma44(Aq0[2], pit[2], mfma44(Aq0[0], pit[0], T(0))) + mfma44(Aq0[1], pit[1], T(0));       // (tile (3,0) of Abar is zero)
+                an[3] = mfma44(Aq1z[2], pit[2], mfma44(Aq1z[0], pit[0], T(0))) + mfma44(Aq1z[3], pit[3], mfma44(Aq1z[1], pit[1], T(0)));
+                NMPC_UNROLL for (int t = 0; t < 4; t++) {
+                    const T v = an[t] - mfma44(o.mn[t], m0, T(0));
+                    pit[t] = (tc == 0 && natR[t] >= 0) ? v : T(0);
+                }
+            }
+        };
+        using Fl = std::integral_constant<bool, false>;
+        using Tr = std::integral_constant<bool, true>;
+        constexpr int H = 2;
+        OpsD oa[H], ob[H];
+        NMPC_UNROLL for (int i = 0; i < H; i++) fetch_d(N - 1 - i, oa[i]);
+        for (int k0 = N - 1; k0 >= kl; k0 -= 2 * H) {
+            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_d(k0 - H - i, ob[i]);
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 - i >= kl) stageD(k0 - i, oa[i], Fl{}); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_d(k0 - 2 * H - i, oa[i]);
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 - H - i >= kl) stageD(k0 - H - i, ob[i], Fl{}); }
+        }
+        if constexpr (LDSC) {
+            if (kl > 0) {
+                OpsD ol, on;
+                fetch_sc(kl - 1, on);
+                for (int k = kl - 1; k >= 0; k--) {
+                    fetch_d_lds(k, ol);
+                    ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
+                    fetch_sc(k - 1, on);
+                    stageD(k, ol, Tr{});
+                }
+            }
+        }
+    };
+    // ================= sweep E: forward homogeneous solve of the corrector, final direction, step length
+    auto sweepE = [&](auto) {
+        T AT2[4], AT3z[4], BT[4];
+        if (SHARED) {
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                const int l = natC[it] >= 0 ? natC[it] : 0;
+                const bool real = natC[it] >= 0;
+                const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta];
+                AT2[it] = real ? a2 : T(0);
+                AT3z[it] = (real && ta < 3) ? a3 : T(0);
+                BT[it] = real ? bb : T(0);
+            }
+        }
+        T xt[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = 0;
+        const T one15 = (ta == 3 && tc == 0) ? T(1) : T(0);        // homogeneous coordinate, for the m term only
+        T rmx = c.tau, dmx = 0;
+        struct OpsE { T mt[4], z, u, ll, lu, ua, ul, ab[SHARED ? 1 : 12]; };
+        const int kl = LDSC ? (lstg < N ? lstg : N) : 0;
+        const int dslot = tc == 0 ? 16 + ta : 20 + ta;
+        auto fetch_sc = [&](int k, OpsE &o) {
+            const T *ivn = tIV + k * IV_ROWS;
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
+        };
+        auto fetch_e = [&](int kq, OpsE &o) {
+            const int k = kq < N ? kq : N - 1;
+            const T *lmn = tLM + k * TLM_ROWS;
+            if (SHARED || k >= kl) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[TLM_MT + jt * 16 + r];
+                o.z = lmn[TLM_Z + r];
+            }
+            fetch_sc(k, o);
+            if (!SHARED) {
+                const T *a = tAB + (size_t)k * TAB_ROWS + rT;
+                NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
+            }
+        };
+        auto fetch_e_lds = [&](int k, OpsE &o) {
+            const T *lmn = sLM + k * LMR;
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) o.mt[jt] = lmn[jt * 16 + r];
+            o.z = lmn[64 + r];
+        };
+        auto stageE = [&](int k, OpsE &o) {
+            if (!SHARED) {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = o.ab[it * 3]; AT3z[it] = ta < 3 ? o.ab[it * 3 + 1] : T(0); BT[it] = o.ab[it * 3 + 2]; }
+                if (LDSC) { if (k < kl) fetch_e_lds(k, o); }
+            }
+            T *ivk = tIV + k * IV_ROWS;
+            T xn[4];
+            xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3z[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);
+            const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
+                      + mfma44(o.mt[3], xt[3] + one15, mfma44(o.mt[1], xt[1], T(0)));
+            const T ut = -mfma44(o.z, v, T(0));
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+            {
+                const Pair<T> pr(o.u, o.ll, o.lu, lb_a - o.ul, ub_a - o.ul);
+                const T da = o.ua - o.u;
+                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
+                const T d = da + ut;
+                ivk[dslot] = d;
+                const T dl = -o.ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                const T du = -o.lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                rmx = fmax(rmx, fmax(-d * pr.itl, d * pr.itu));
+                rmx = fmax(rmx, fmax(-dl * fast_rcp(o.ll), -du * fast_rcp(o.lu)));
+                dmx = fmax(dmx, fabs(d) * iw_a);
+            }
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = xn[t];
+        };
+        constexpr int H = 2;
+        OpsE oa[H], ob[H];
+        const int kb = SHARED ? kl : 0;
+        NMPC_UNROLL for (int i = 0; i < H; i++) fetch_e(kb + i, oa[i]);
+        if constexpr (LDSC && SHARED) {
+            if (kl > 0) {
+                OpsE ol, on;
+                fetch_sc(0, on);
+                fetch_e_lds(0, ol);
+                for (int k = 0; k < kl; k++) {
+                    ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
+                    fetch_sc(k + 1 < N ? k + 1 : k, on);
+                    stageE(k, ol);
+                    if (k + 1 < kl) fetch_e_lds(k + 1, ol);
+                }
+            }
+        }
+        for (int k0 = kb; k0 < N; k0 += 2 * H) {
+            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_e(k0 + H + i, ob[i]);
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + i < N) stageE(k0 + i, oa[i]); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) fetch_e(k0 + 2 * H + i, oa[i]);
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + H + i < N) stageE(k0 + H + i, ob[i]); }
+        }
+        rmaxE = rmx; dmaxE = dmx;
+    };
+    // ================= sweep F: primal-dual update, duality measure of the new iterate, active-set guess for a later attempt
+    T msF = 0;
+    auto sweepF = [&](T alpha) {
+        T ms = 0;
+        constexpr int CHF = 10;
+        const int us = tc == 0 ? ta : 20 + ta, ls = tc == 0 ? 4 + ta : 20 + ta, hs = tc == 0 ? 8 + ta : 20 + ta, ps = tc == 0 ? 16 + ta : 20 + ta;
+        for (int k0 = 0; k0 < N; k0 += CHF) {
+            T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_ua[CHF], f_d[CHF];
+            NMPC_UNROLL for (int i = 0; i < CHF; i++) {
+                const int k = (k0 + i < N) ? k0 + i : N - 1;
+                const T *ivn = tIV + k * IV_ROWS;
+                f_ul[i] = ulin(k, ta);
+                f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
+            }
+            NMPC_UNROLL for (int i = 0; i < CHF; i++) {
+                const int k = k0 + i;
+                if (k < N) {
+                    T *ivk = tIV + k * IV_ROWS;
+                    T u = f_u[i], ll = f_ll[i], lu = f_lu[i];
+                    const T lo = lb_a - f_ul[i], hi = ub_a - f_ul[i];
+                    const Pair<T> pr(u, ll, lu, lo, hi);
+                    const T da = f_ua[i] - u, d = f_d[i];
+                    const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                    const T cl = dla * da, cu = -dua * da;
+                    const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                    const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
+                    ivk[us] = u; ivk[ls] = ll; ivk[hs] = lu;
+                    // active-set guess for a later attempt: a bound whose multiplier exceeds its slack
+                    ivk[ps] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
+                    ms += ll * (u - lo) + lu * (hi - u);
+                }
+            }
+        }
+        msF = ms;
+    };
+    // ================= state rollout from the inputs of the iterate (an instance that ends on the interior-point iterate): xhat_k
+    // for the output sweep, NaN check of the step
+    bool roll_bad = false;
+    auto rollout = [&](auto) {
+        T AT2[4], AT3[4], BT[4];
+        auto tiles_T = [&](int k) {
+            if (SHARED) {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                    const int l = natC[it] >= 0 ? natC[it] : 0;
+                    const bool real = natC[it] >= 0;
+                    const T a2 = sAd[l * 8 + ta], a3 = sAd[l * 8 + 4 + (ta < 3 ? ta : 0)], bb = sB[l * 4 + ta], bv_ = sbv[l];
+                    AT2[it] = real ? a2 : T(0);
+                    AT3[it] = real ? (ta < 3 ? a3 : bv_) : ((it == 3 && tc == 3 && ta == 3) ? T(1) : T(0));
+                    BT[it] = real ? bb : T(0);
+                }
+            } else {
+                const T *a = tAB + (size_t)k * TAB_ROWS + rT;
+                NMPC_UNROLL for (int it = 0; it < 4; it++) { AT2[it] = a[(it * 3) * 16]; AT3[it] = a[(it * 3 + 1) * 16]; BT[it] = a[(it * 3 + 2) * 16]; }
+            }
+        };
+        if (SHARED) tiles_T(0);
+        T xt[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+        int xslot[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
+        bool bad = false;
+        for (int k = 0; k < N; k++) {
+            if (!SHARED) tiles_T(k);
+            const T uk = tIV[k * IV_ROWS + ta];
+            const T ut = tc == 0 ? uk : T(0);
+            bad |= !(uk == uk) || fabs(uk) > T(1e300);
+            if (TRAJ) {
+                T *xs = tLM + k * TLM_ROWS + 66;
+                NMPC_UNROLL for (int t = 0; t < 4; t++) xs[xslot[t]] = xt[t];
+            }
+            T xn[4];
+            xn[0] = xt[0] + dt_v * xt[1]; xn[1] = xt[1]; xn[2] = 0; xn[3] = 0;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);
+            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
+            NMPC_UNROLL for (int t = 0; t < 4; t++) { xt[t] = xn[t]; bad |= (tc == 0 && natR[t] >= 0) && (!(xn[t] == xn[t]) || fabs(xn[t]) > T(1e300)); }
+        }
+        if (tc == 0) {
+            NMPC_UNROLL for (int t = 0; t < 4; t++)
+                if (natR[t] >= 0) sXh[natR[t]] = xt[t];
+        }
+        NMPC_WSYNC();
+        const T xN = sXh[rr];
+        if (TRAJ) { if (rowl) tLM[66 + rr] = xN; }
+        roll_bad = bad;
+    };
+
+    // ================= one active-set pass of every team of the wave that is in an attempt (mode M_POL)
+    auto as_pass = [&]() {
+        pol = mode == M_POL;
+        tLM = pol ? tLM_own : tLM_spare; tIV = pol ? tIV_own : tIV_spare; tP = pol ? tP_own : tP_spare;
+        // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
+        ks = N - 1;
+        if (tP && pass > 0) {
+            if (r == 0) { sRed[28] = (T)(pol ? k_top : -1); sRed[29] = (T)(pol ? ck_valid : N); }
+            __syncthreads();
+            ks = 0;
+            int vmin = N;            // every live team must own the checkpoint the wave resumes from
+            for (int t = 0; t < 4; t++) {
+                const int kt = (int)smem[t * LDS_T + A_RED + 28], vt = (int)smem[t * LDS_T + A_RED + 29];
+                ks = kt > ks ? kt : ks;
+                vmin = vt < vmin ? vt : vmin;
+            }
+            if (ks >= vmin) ks = N - 1;
+            ks = __builtin_amdgcn_readfirstlane(ks);
+        }
+        // checkpoint window of this pass (see team_ipm): two stages in the first pass, the configured window after
+        wnd = pass_in_attempt == 0 ? (ckpt < 2 ? ckpt : 2) : ckpt;
+        if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
+
+        ok = true; nanp = false; gm = 0;
+        if (nopins_pass) sweepA(NoPins{}, NoIpm{}); else sweepA(WithPins{}, NoIpm{});
+        NMPC_STAMP(0)
+        __syncthreads();
+        // growth certificate: the team-wide max |B'PB| of this sweep against that of the first factorisation of the solve
+        sh[r] = gm;
+        NMPC_WSYNC();
+        T gt = sh[0];
+        NMPC_UNROLL for (int i = 1; i < 16; i++) gt = fmax(gt, sh[i]);
+        if (pol && gbase == T(0)) gbase = gt;
+        const bool trip = pol && c.growth_max > T(0) && gt > c.growth_max * gbase;
+        bool pol_fail = false;
+        if (pol && !ok) {
+            // A NaN pivot with nothing pinned (first pass) means NaN data: status 1.  In a later pass it can be the pinned
+            // recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per
+            // stage there - and is one more way for the attempt to fail: the interior point iteration takes over, as in the
+            // oracle (ocpqp_polish breaks out of a pass that produced a NaN)
+            if (nanp && nopins_pass) { status = 1; mode = M_DONE; }
+            else pol_fail = true;                       // give up this attempt
+        }
+        if (trip) { pol_fail = true; tripped = true; }  // not accurate enough to be accepted (see qp_growth_max): the attempt fails
+        pol2 = mode == M_POL;
+
+        viol = false; heavy = false; kchgB = -1; xh = 0;
+        if (nopins_pass) sweepB(NoPins{}, NoIpm{}); else sweepB(WithPins{}, NoIpm{});
         NMPC_STAMP(1)
         if (TRAJ) { if (rowl) tLM[66 + rr] = xh; }      // xhat_N parks in the unused xhat_0 slot (output sweep)
         __syncthreads();
@@ -764,42 +1137,187 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             npol++;
             pass_in_attempt++;
             const bool unclean = pol_fail || t_viol || t_heavy;
-            if (!unclean) mode = M_DONE;                  // the pass satisfies the KKT conditions of the QP: accepted
+            if (!unclean) { mode = M_DONE; from_ua = true; }   // the pass satisfies the KKT conditions of the QP: accepted
             else if (pol_fail || t_heavy || pass_in_attempt >= polish_passes) mode = M_GIVEUP;
             else k_top = kc < ck_valid ? kc : N - 1;
         }
         pass++;
         __syncthreads();   // sRed / sXh are reused by the next pass
+    };
+
+    int it = 0;              // interior-point iterations taken
+    if constexpr (MODE == 0) {
+        for (;;) {
+            if (__ballot(mode == M_POL) == 0) break;
+            nopins_pass = pass == 0;
+            as_pass();
+        }
+    } else {
+        // ---- phases of a wave: interior-point iterations for the teams in that mode until each has converged, failed or
+        // reached the threshold of its next attempt; then active-set passes for the teams that wait for an attempt (the
+        // others idle in the spare row either way).  A team's own sequence of sweeps never depends on its wave-mates.
+        const T nc = T(2 * NU) * T(N);
+        T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu, step_last = 0;
+        bool have_point = false;
+        const bool attempt_first = MODE == 1 && c.polish && c.polish_budget > 0 && c.polish_passes > 0 && c.polish_mu >= c.mu0;
+        bool first_free = attempt_first; // wave-uniform: the first active-set phase starts from "all inputs free"
+        if (MODE == 2) {                 // the first attempt was made - and given up - by the active-set kernel
+            const int np0 = w.npol[inst];
+            npol = np0 < 0 ? -np0 : np0;
+            pol_mu *= T(1e-2);
+            gbase = w.gbase[inst];
+            mode = valid ? M_IPM : M_DONE;
+        } else {
+            mode = valid ? (attempt_first ? M_WAIT : M_IPM) : M_DONE;
+        }
+        const int polish_budget = c.polish_budget, iter_max = c.iter_max > 0 ? c.iter_max : 1;
+        for (;;) {
+            // ---------------- interior-point phase
+            for (;;) {
+                if (mode == M_IPM) {
+                    if (!(mu == mu)) { status = 1; mode = M_DONE; }
+                    else if (mu <= c.tol_comp && rho <= c.tol_stat && (it == 0 || !(c.tol_step > T(0)) || step_last <= c.tol_step)) mode = M_DONE;
+                    else if (c.polish && mu <= pol_mu && npol < polish_budget) mode = M_WAIT;
+                    else if (it >= iter_max) { status = 2; mode = M_DONE; }
+                }
+                if (__ballot(mode == M_IPM) == 0) break;
+                const bool ipm = mode == M_IPM;
+                if (ipm) it++;
+                if (__ballot(ipm && !have_point) != 0) {      // first interior-point iteration of some team
+                    init_point(valid && ipm && !have_point);
+                    __syncthreads();
+                }
+                have_point |= ipm;
+                pol = false; pol2 = false;
+                tLM = ipm ? tLM_own : tLM_spare; tIV = ipm ? tIV_own : tIV_spare; tP = tP_spare;
+                ks = N - 1; wnd = -1;
+                ok = true; nanp = false; gm = 0;
+                sweepA(NoPins{}, Ipm{});
+                NMPC_STAMP(0)
+                __syncthreads();
+                sh[r] = gm;
+                NMPC_WSYNC();
+                T gt = sh[0];
+                NMPC_UNROLL for (int i = 1; i < 16; i++) gt = fmax(gt, sh[i]);
+                if (ipm && ok && gbase == T(0)) gbase = gt;
+                const bool trip = ipm && ok && c.growth_max > T(0) && !(gt <= c.growth_max * gbase);
+                if (ipm && (!ok || trip)) {
+                    // this factorisation cannot be used: the QP ends at the current iterate - solved if that is within the
+                    // acceptable tolerances, a failure otherwise (oracle ocpqp_ipm)
+                    status = (mu <= c.acc_comp && rho <= c.acc_stat) ? 0 : ((!ok && nanp) ? 1 : 4);
+                    tripped |= trip;
+                    mode = M_DONE;
+                }
+                const bool ipm2 = mode == M_IPM;
+                tLM = ipm2 ? tLM_own : tLM_spare; tIV = ipm2 ? tIV_own : tIV_spare;
+                viol = false; heavy = false; kchgB = -1; xh = 0;
+                sweepB(NoPins{}, Ipm{});
+                NMPC_STAMP(1)
+                __syncthreads();
+                {
+                    const T rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
+                    const T s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
+                    const T aaff = T(1) / rmax;
+                    const T muaff = (T(1) - aaff) * mu + aaff * aaff * s2 / nc;
+                    T sg3 = muaff / mu;
+                    sg3 = sg3 * sg3 * sg3;
+                    sigmu = sg3 * mu;
+                }
+                sweepD(Ipm{});
+                NMPC_STAMP(2)
+                __syncthreads();
+                sweepE(Ipm{});
+                NMPC_STAMP(3)
+                if (tc == 0) { sRed[12 + ta] = rmaxE; sRed[20 + ta] = dmaxE; }
+                __syncthreads();
+                const T rmx = fmax(fmax(sRed[12], sRed[13]), fmax(sRed[14], sRed[15]));
+                const T dmx = fmax(fmax(sRed[20], sRed[21]), fmax(sRed[22], sRed[23]));
+                const T alpha = c.tau / rmx;
+                sweepF(alpha);
+                NMPC_STAMP(4)
+                if (tc == 0) sRed[16 + ta] = msF;
+                __syncthreads();
+                const T ms = sRed[16] + sRed[17] + sRed[18] + sRed[19];
+                if (ipm2) {
+                    if (!(alpha == alpha)) { status = 1; mode = M_DONE; }
+                    else if (alpha < T(1e-12)) { status = 3; mode = M_DONE; }
+                    else {
+                        rho *= (T(1) - alpha);
+                        mu = ms / nc;
+                        step_last = alpha * dmx;
+                    }
+                }
+                __syncthreads();   // sRed is reused by the next iteration
+            }
+            // ---------------- active-set phase: the teams that wait for an attempt
+            if (__ballot(mode == M_WAIT) != 0) {
+                if (mode == M_WAIT) { mode = M_POL; pass_in_attempt = 0; k_top = N - 1; ck_valid = 0; }
+                pass = 0;
+                for (;;) {
+                    if (__ballot(mode == M_POL) == 0) break;
+                    nopins_pass = first_free && pass == 0;
+                    as_pass();
+                }
+                first_free = false;
+                if (mode == M_GIVEUP) {       // the interior point iteration takes over (or resumes); next attempt 100x further down
+                    mode = M_IPM;
+                    pol_mu *= T(1e-2);
+                    if (tripped) npol = polish_budget;
+                }
+            }
+            if (__ballot(mode != M_DONE) == 0) break;
+        }
     }
 
-    // ---- outputs.  Accepted: the forward sweep left the candidate inputs (and xhat_k), the full step (U1) is
-    // applied stage-parallel into the caller's arrays.  NaN (status 1): zeros and the cold-start point.
-    // Given up: the general kernel solves the instance from scratch and writes everything.
+    // ---- outputs.  Accepted active-set solution: the forward sweep left the candidate inputs (and xhat_k); interior-point
+    // iterate: the inputs of the iterate, states by the rollout above.  The full step (U1) is applied stage-parallel into the
+    // caller's arrays.  Failure (NaN: status 1, QP failure: 4, reported iteration cap: 2): zeros and the cold-start point.
+    // Given up (MODE 0): the work-list launch continues the instance and writes everything.
     NMPC_STAMP(6)
+    int nlp_status = status;
+    if constexpr (MODE != 0) {
+        // QP status -> acados numbering (oracle orc_sqp_rti): iteration cap tolerated or reported (U10 switch), min step -> QP failure
+        nlp_status = status == 2 ? (c.maxiter_status ? 2 : 0) : (status == 3 ? 4 : status);
+        const bool need_roll = valid && !from_ua && nlp_status == 0;
+        if (__ballot(need_roll) != 0) {
+            tLM = need_roll ? tLM_own : tLM_spare; tIV = need_roll ? tIV_own : tIV_spare;
+            rollout(Ipm{});
+            __syncthreads();
+            const bool t_bad = (__ballot(roll_bad) & team_mask) != 0;
+            if (need_roll && t_bad) nlp_status = 1;          // NaN anywhere in the step poisons the instance
+        }
+    }
     NMPC_PROF_END(w)
     tLM = tLM_own; tIV = tIV_own;
     if (!valid) return;
-    if (mode == M_GIVEUP) {
+    if (MODE == 0 && mode == M_GIVEUP) {
         if (r == 0) {
-            w.npol[inst] = -npol;                          // the general kernel resumes its pass budget from here
+            // the work-list launch resumes the pass budget from here (all of it spent when the growth certificate ended the
+            // attempt: the same pins would fail the same way) and compares against the same first factorisation
+            w.npol[inst] = -(tripped ? c.polish_budget : npol);
+            w.gbase[inst] = gbase;
             const int slot = atomicAdd(wl.count, 1);
             wl.list[slot] = inst;
         }
         return;
     }
-    const bool accepted = status == 0;
+    const bool accepted = nlp_status == 0;
+    const int uoff = from_ua ? 12 : 0;                 // candidate inputs of the accepted pass | inputs of the iterate
     if (r == 0) {
-        if (out.status) out.status[inst] = status;
-        w.iters[inst] = 0; w.status[inst] = status; w.npol[inst] = accepted ? npol : -npol;
+        if (out.status) out.status[inst] = nlp_status;
+        w.iters[inst] = it; w.status[inst] = nlp_status; w.npol[inst] = (accepted && from_ua) ? npol : -npol;
     }
-    if (tc == 0) out.u0[(size_t)inst * NU + ta] = (TI)(accepted ? ulin(0, ta) + u0_cand : T(0));   // controller.py:448-452
+    if (tc == 0) {                                     // controller.py:448-452
+        const T du0 = from_ua ? u0_cand : tIV[ta];
+        out.u0[(size_t)inst * NU + ta] = (TI)(accepted ? ulin(0, ta) + du0 : T(0));
+    }
     if (TRAJ) {
         constexpr int CH = 8;
         for (int k0 = 0; k0 <= N; k0 += CH) {
             T uv[CH], ulv[CH], xlv[CH], xhv[CH];
             NMPC_UNROLL for (int i = 0; i < CH; i++) {
                 const int k = (k0 + i <= N) ? k0 + i : N, ku = k < N ? k : N - 1;
-                uv[i] = tIV[ku * IV_ROWS + 12 + j];
+                uv[i] = tIV[ku * IV_ROWS + uoff + j];
                 ulv[i] = ulin(ku, j);
                 xlv[i] = xlin(k);
                 xhv[i] = tLM[(k < N ? k * TLM_ROWS : 0) + 66 + rr];      // xhat_N sits in the stage-0 slot

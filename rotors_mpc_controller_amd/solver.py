@@ -174,6 +174,21 @@ class NmpcOcpSolver:
         """int32 [B] on the device: active-set passes of the last solve (> 0: accepted active-set solution)."""
         return int(self._lib.nmpc_device_passes(self._h) or 0)
 
+    def counts(self, B: int | None = None):
+        """(iterations, passes) per instance of the last solve, host int32 arrays.  passes > 0: the instance ended on an
+        accepted active-set solution after that many passes; <= 0: on the interior-point iterate (magnitude = passes spent)."""
+        n = int(B if B is not None else self.stats()["batch"])
+        it, ps = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        ip = C.POINTER(C.c_int32)
+        self._check(self._lib.nmpc_get_counts(self._h, n, it.ctypes.data_as(ip), ps.ctypes.data_as(ip)))
+        return it, ps
+
+    def iterations(self, B: int | None = None):
+        return self.counts(B)[0]
+
+    def passes(self, B: int | None = None):
+        return self.counts(B)[1]
+
     def set_timing(self, on: bool) -> None:
         """HIP events around the kernels of every solve (default on; stats() then reports kernel times)."""
         self._check(self._lib.nmpc_set_timing(self._h, int(bool(on))))
