@@ -377,6 +377,7 @@ static void trsv_lower_t(const double *L, int m, double *y)
 
 typedef struct {
     double **L, **M, **m; /* per stage: chol(Huu) nu*nu, L^{-1}Hux nu*nx, L^{-1}gu nu */
+    double **P, **p;      /* optional (NULL or N+1 entries): the cost-to-go (P_k nx*nx, p_k nx) a factor pass leaves, k = 0..N */
 } ricc_fact;
 
 /* Backward Riccati sweep.  factor != 0: build L,M from D (= R + diag(sig)) and the data;
@@ -391,6 +392,7 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
     if (gmax) *gmax = 0.0;
     if (factor) memcpy(P, p->QN, sizeof(P));
     for (int i = 0; i < NX; i++) pv[i] = homogeneous ? 0.0 : p->qN[i];
+    if (factor && f->P) { memcpy(f->P[N], P, sizeof(P)); memcpy(f->p[N], pv, sizeof(pv)); }
     /* In the factor pass P holds P_{k+1}.  In a vector-only pass (factor == 0) the
      * homogeneous recursion needs no P at all (b = 0).                                   */
     for (int k = N - 1; k >= 0; k--) {
@@ -472,6 +474,7 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
             for (int l = 0; l < m; l++) s -= M[l * NX + i] * mv[l];
             pv[i] = s;
         }
+        if (factor && f->P) { memcpy(f->P[k], P, sizeof(P)); memcpy(f->p[k], pv, sizeof(pv)); }
         free(PB);
         free(gu);
     }
@@ -526,6 +529,13 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
     int **pin = (int **)malloc(sizeof(int *) * N), **newpin = (int **)malloc(sizeof(int *) * N);
     double **gsave = (double **)malloc(sizeof(double *) * N);
     double *xh = dalloc((size_t)(N + 1) * NX);
+    /* the cost-to-go of every pass is kept: the multiplier of a pinned input is formed with the costate P_{k+1} x_{k+1} + p_{k+1}.
+     * (The adjoint recursion pi_k = Q x + q + A'pi_{k+1} gives the same number in exact arithmetic but amplifies rounding by
+     * rho(A) per stage: on a violently unstable plant - rho = 2, N = 120 - it accepted active sets whose multipliers, solved in
+     * 60 digits, had the wrong sign by 8e-2, where the tile kernels' P-based check went on to the right set.)                  */
+    ricc_fact fp = *f;
+    fp.P = (double **)malloc(sizeof(double *) * (size_t)(N + 1)); fp.p = (double **)malloc(sizeof(double *) * (size_t)(N + 1));
+    for (int k = 0; k <= N; k++) { fp.P[k] = dalloc(NX * NX); fp.p[k] = dalloc(NX); }
     for (int k = 0; k < N; k++) {
         const int nu = p->nu[k];
         m.B[k] = dalloc((size_t)NX * nu); m.b[k] = dalloc(NX); m.R[k] = dalloc((size_t)nu * nu);
@@ -579,20 +589,20 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         }
         (*passes)++;
         double g = 0.0;
-        if (riccati_backward(&m, zero, m.r, 0, 1, (ricc_fact *)f, &g)) break;
+        if (riccati_backward(&m, zero, m.r, 0, 1, &fp, &g)) break;
         if (*gbase == 0.0) *gbase = g;
         if (*gbase > 0.0 && g / *gbase > *growth) *growth = g / *gbase;
         if (growth_max > 0.0 && g > growth_max * *gbase) { *untrusted = 1; break; }
         riccati_forward(&m, f, dx0, 0, uh, xh);
-        double pi[NX], pin_[NX];
+        double pi[NX];
         int changed = 0, nanf = 0;
-        for (int i = 0; i < NX; i++) {
-            double s2 = p->qN[i];
-            for (int j = 0; j < NX; j++) s2 += p->QN[i * NX + j] * xh[N * NX + j];
-            pi[i] = s2;
-        }
         for (int k = N - 1; k >= 0; k--) {
             const int nu = p->nu[k];
+            for (int i = 0; i < NX; i++) {          /* costate of the pinned problem at stage k + 1 */
+                double s2 = fp.p[k + 1][i];
+                for (int j = 0; j < NX; j++) s2 += fp.P[k + 1][i * NX + j] * xh[(k + 1) * NX + j];
+                pi[i] = s2;
+            }
             for (int i = 0; i < nu; i++)
                 if (pin[k][i]) uh[k][i] = pin[k][i] < 0 ? p->lo[k][i] : p->hi[k][i];
             for (int i = 0; i < nu; i++) {
@@ -613,13 +623,6 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
                     else newpin[k][i] = 0;
                 }
             }
-            for (int i = 0; i < NX; i++) {
-                double s2 = p->q[k][i];
-                for (int j = 0; j < NX; j++) s2 += p->Q[k][i * NX + j] * xh[k * NX + j] + p->A[k][j * NX + i] * pi[j];
-                for (int j = 0; j < nu; j++) s2 += p->S[k][j * NX + i] * uh[k][j];
-                pin_[i] = s2;
-            }
-            memcpy(pi, pin_, sizeof(pi));
         }
         for (int i = 0; i < (N + 1) * NX; i++) if (!(xh[i] == xh[i])) nanf = 1;
         if (nanf) break;
@@ -639,6 +642,8 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         free(m.B[k]); free(m.b[k]); free(m.R[k]); free(m.S[k]); free(m.q[k]); free(m.r[k]);
         free(zero[k]); free(uh[k]); free(pin[k]); free(newpin[k]); free(gsave[k]);
     }
+    for (int k = 0; k <= N; k++) { free(fp.P[k]); free(fp.p[k]); }
+    free(fp.P); free(fp.p);
     free(newpin); free(gsave);
     free(m.B); free(m.b); free(m.R); free(m.S); free(m.q); free(m.r); free(zero); free(uh); free(pin); free(xh);
     return ok;
@@ -658,6 +663,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     f.L = (double **)malloc(sizeof(double *) * N);
     f.M = (double **)malloc(sizeof(double *) * N);
     f.m = (double **)malloc(sizeof(double *) * N);
+    f.P = NULL; f.p = NULL;
     double **ll = (double **)malloc(sizeof(double *) * N), **lu = (double **)malloc(sizeof(double *) * N);
     double **sig = (double **)malloc(sizeof(double *) * N), **rh = (double **)malloc(sizeof(double *) * N);
     double **ua = (double **)malloc(sizeof(double *) * N), **du = (double **)malloc(sizeof(double *) * N);
@@ -1038,6 +1044,15 @@ int orc_solve_batch(const orc_config *c, int Bn, const double *x0, const double 
                     double *u0, int *status, double *x_out, double *u_out,
                     int *iters, int nthreads)
 {
+    return orc_solve_batch_ex(c, Bn, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, iters, NULL, NULL, nthreads);
+}
+
+int orc_solve_batch_ex(const orc_config *c, int Bn, const double *x0, const double *yref,
+                       const double *yref_e, int yref_bcast,
+                       const double *x_init, const double *u_init,
+                       double *u0, int *status, double *x_out, double *u_out,
+                       int *iters, int *passes, double *growth, int nthreads)
+{
     const int N = c->N;
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -1063,6 +1078,8 @@ int orc_solve_batch(const orc_config *c, int Bn, const double *x0, const double 
         const int s = orc_sqp_rti(c, x0i, yr, ye, xt, ut, &st);
         if (status) status[ib] = s;
         if (iters) iters[ib] = st.qp_iter;
+        if (passes) passes[ib] = (s == 0 && st.polished) ? st.polish_attempts : -st.polish_attempts;   /* the library's convention (nmpc_device_passes) */
+        if (growth) growth[ib] = st.growth;
         for (int i = 0; i < NU; i++) u0[(size_t)ib * NU + i] = (s == 0) ? ut[i] : 0.0; /* controller.py:448-450 */
         if (s != 0) { /* the warm start is invalidated (controller.py:448-450): hand back the cold-start point (:425-431) */
             for (int k = 0; k <= N; k++) memcpy(xt + (size_t)k * NX, x0i, sizeof(double) * NX);

@@ -138,6 +138,15 @@ int orc_solve_batch(const orc_config *c, int B, const double *x0, const double *
                     double *u0, int *status, double *x_out, double *u_out,
                     int *iters, int nthreads);
 
+/* the same with two more per-instance outputs (nullable): passes = active-set passes spent, > 0 when the instance ended on an
+ * accepted active-set solution, <= 0 when on the interior-point iterate (the library's nmpc_device_passes convention);
+ * growth = largest g / g_first of the growth certificate                                                                     */
+int orc_solve_batch_ex(const orc_config *c, int B, const double *x0, const double *yref,
+                       const double *yref_e, int yref_bcast,
+                       const double *x_init, const double *u_init,
+                       double *u0, int *status, double *x_out, double *u_out,
+                       int *iters, int *passes, double *growth, int nthreads);
+
 #ifdef __cplusplus
 }
 #endif

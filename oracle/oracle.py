@@ -81,6 +81,8 @@ def lib():
         _lib.orc_solve_batch.argtypes = [cp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, dp, dp,
                                          ip, C.c_int]
         _lib.orc_solve_batch.restype = C.c_int
+        _lib.orc_solve_batch_ex.argtypes = [cp, C.c_int, dp, dp, dp, C.c_int, dp, dp, dp, ip, dp, dp, ip, ip, dp, C.c_int]
+        _lib.orc_solve_batch_ex.restype = C.c_int
     return _lib
 
 
@@ -191,9 +193,11 @@ def solve_batch(c, x0, yref, yref_e, x_init=None, u_init=None, want_traj=False, 
     uo = np.zeros((B, N, NU)) if want_traj else None
     xi = None if x_init is None else f64(x_init)
     ui = None if u_init is None else f64(u_init)
-    lib().orc_solve_batch(C.byref(c), B, _p(x0), _p(yref), _p(yref_e), bcast, _p(xi), _p(ui),
-                          _p(u0), _ip(status), _p(xo), _p(uo), _ip(iters), int(nthreads))
-    return dict(u0=u0, status=status, iters=iters, x=xo, u=uo)
+    passes = np.zeros(B, dtype=np.int32)
+    growth = np.zeros(B)
+    lib().orc_solve_batch_ex(C.byref(c), B, _p(x0), _p(yref), _p(yref_e), bcast, _p(xi), _p(ui),
+                             _p(u0), _ip(status), _p(xo), _p(uo), _ip(iters), _ip(passes), _p(growth), int(nthreads))
+    return dict(u0=u0, status=status, iters=iters, x=xo, u=uo, passes=passes, growth=growth)
 
 
 def hover_yref(c, pos=(0.0, 0.0, 1.0), yaw=0.0):

@@ -17,6 +17,7 @@ struct AsLaunch {
     TeamWork<double> tw;
     WorkList wl;
     int B, tpw, lds_stride, lstg, occ;
+    int lm_off = 0;             // LDS offset (doubles) of a team's stage cache behind its working arrays
     int kind = 0;               // 0: k_team_as (first attempt), 1: k_team_qp (whole QP, whole batch), 2: k_team_qp_list (work list)
     int nlist = 0;              // workgroups of the work-list launch
     bool shared, traj;

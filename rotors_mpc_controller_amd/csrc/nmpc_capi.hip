@@ -371,17 +371,24 @@ const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : 
 
 }  // extern "C"
 
+// working arrays of a team in front of its stage cache, in doubles (more than two integrator steps: the evaluation points of
+// the shared linearisation's single stage take the larger layout, EvLayout<AS_MAX_STEPS>)
+static int as_lds_base(const nmpc_solver *s, bool shared)
+{
+    return shared ? TEAM_AS_LDS_SHARED + (s->cfg.sim_num_steps > 2 ? AS_EV : 0) : TEAM_AS_LDS_STAGE;
+}
+
 // LDS carve of the kernels that iterate the interior point method (k_team_qp, k_team_qp_list: one wave per SIMD, 40 KB per wave):
 // stage cache rows of IP_LM_ROWS doubles, team stride 192 B past a multiple of the 256-B bank row
 static void qp_lds(const nmpc_solver *s, bool shared, AsLaunch &a)
 {
-    const int base = shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    const int base = as_lds_base(s, shared);
     const int per_team = 40960 / 4 / (int)sizeof(double);
     int lstg = std::max(0, std::min(s->cfg.N, (per_team - base - 31) / IP_LM_ROWS));
     if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
     int stride = base + lstg * IP_LM_ROWS;
     stride += (24 - stride % 32 + 32) % 32;
-    a.lstg = lstg; a.lds_stride = stride; a.lds_bytes = (size_t)4 * stride * sizeof(double);
+    a.lstg = lstg; a.lds_stride = stride; a.lm_off = base; a.lds_bytes = (size_t)4 * stride * sizeof(double);
 }
 
 // Default FP64 path: the active-set kernel makes the first attempt of every instance; the general kernel runs on the work
@@ -408,7 +415,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD) holds the
     // factors of the first stages; the team stride stays 192 B past a multiple of the 256-B bank row (24 doubles mod 32).
     // The two-waves build carries no cache.
-    const int base_as = c.shared ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;
+    const int base_as = as_lds_base(s, c.shared != 0);
     const int per_team = 40960 / 4 / (int)sizeof(double);
     int lstg = occ_as == 2 ? 0 : std::max(0, std::min(s->cfg.N, (per_team - base_as - 31) / AS_LM_ROWS));
     if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
@@ -417,7 +424,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
     AsLaunch al;
     al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
-    al.lds_stride = lds_stride; al.lstg = lstg; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
+    al.lds_stride = lds_stride; al.lstg = lstg; al.lm_off = base_as; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
     al.lds_bytes = lds_as; al.stream = st;
     HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));

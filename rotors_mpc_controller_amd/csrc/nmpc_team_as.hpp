@@ -36,8 +36,16 @@ namespace nmpc {
 
 constexpr int AS_CH = 8;             // stages linearised per chunk (per-stage variant); lanes r < AS_CH integrate
 constexpr int AS_EV = 56;            // doubles per stage in the evaluation-point buffer: 2 steps x 2 points x 7 | t2 | b_k | R e3 / m at the 4 points | 0
-constexpr int EV_T2 = 28, EV_B = 29, EV_RE = 42, EV_ZERO = 54;
-constexpr int AS_MAX_STEPS = 2;      // sim_method_num_steps this kernel is built for (controller.py:188)
+constexpr int AS_MAX_STEPS = 4;      // sim_method_num_steps these kernels are built for (controller.py:188 sets 2).  More than two
+                                     // integrator steps take a second layout of the evaluation-point buffer - twice the room per
+                                     // stage, half the stages per chunk, so the LDS carve is the same (the shared variant's single
+                                     // stage takes 56 doubles more: the host places the stage cache accordingly, lm_off)
+// layout of one stage's evaluation points for at most MS integrator steps: MS x 2 points x 7 | t2 | b_k (13) | R e3 / m at the 2 MS points | 0
+template <int MS> struct EvLayout {
+    static constexpr int T2 = MS * 14, Bk = T2 + 1, RE = Bk + 13, ZERO = RE + MS * 6;
+    static constexpr int STRIDE = MS <= 2 ? AS_EV : 2 * AS_EV;      // 55 of 56, 95 of 112 doubles used
+    static constexpr int CHUNK = MS <= 2 ? 8 : 4;                   // stages linearised per chunk (per-stage variant)
+};
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 constexpr int IP_LM_ROWS = 88;       // ... of the kernels that also iterate the interior point method: | 1 / d_a of H_uu = L D L' (4) | pad
 constexpr int TLM_RINV = 52;         // the same four reciprocals in a stage's HBM row (52..63: the slot of the row form's L | m, unused here)
@@ -92,9 +100,9 @@ struct WorkList {
 template <bool SHARED, bool TRAJ, bool LDSC, class TI, int MODE = 0>
 __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
                                         const Outputs<TI> &out, const TeamWork<double> &tw, const WorkList &wl,
-                                        int B, int tpw, double *smem, int lds_stride, int lstg, int inst_ov = -2)
+                                        int B, int tpw, double *smem, int lds_stride, int lstg, int lm_off, int inst_ov = -2)
 {
-    // lds_stride: doubles of LDS per team (carve below + the stage cache); lstg: the factors of stages 0 .. lstg-1 -
+    // lds_stride: doubles of LDS per team (carve below + the stage cache at lm_off: [lstg][LMR]); lstg: the factors of stages 0 .. lstg-1 -
     // written last by the backward sweep and read first by the forward sweep - stay in LDS and never reach HBM
     // SHARED: cold start with one linearisation for all stages (x_k = x0, u_k = 0 folded at compile time)
     // TRAJ:   the caller wants x_out / u_out: the forward sweep also leaves xhat_k and every candidate input
@@ -104,7 +112,6 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     using T = double;
     using NoPins = std::integral_constant<bool, false>;
     using WithPins = std::integral_constant<bool, true>;
-    constexpr int A_LM = SHARED ? TEAM_AS_LDS_SHARED : TEAM_AS_LDS_STAGE;      // stage cache: [lstg][LMR]
     constexpr int LMR = MODE == 0 ? AS_LM_ROWS : IP_LM_ROWS;
     const int LDS_T = lds_stride;
     NMPC_PROF_BEGIN
@@ -121,7 +128,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     const int N = c.N;
     T *S = smem + team * LDS_T;
     T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sD = S + A_D, *sh = S + A_H, *sXh = S + A_XH;
-    T *sRed = S + A_RED, *sEv = S + A_EV, *sLM = S + A_LM;
+    T *sRed = S + A_RED, *sEv = S + A_EV, *sLM = S + lm_off;
     const bool warm = !SHARED && in.x_init != nullptr && in.u_init != nullptr;
     const TI *x0p = in.x0 + (size_t)inst * NX;
     const TI *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
@@ -171,7 +178,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     NMPC_STAMP(2)
 
     // =========================== preparation: linearise Ns shooting intervals
-    {
+    auto prepare = [&](auto ms_tag) {
+        using EV = EvLayout<decltype(ms_tag)::value>;
+        constexpr int AS_EV = EV::STRIDE, EV_T2 = EV::T2, EV_B = EV::Bk, EV_RE = EV::RE, EV_ZERO = EV::ZERO, AS_CH = EV::CHUNK;
         const int Ns = SHARED ? 1 : N;
         JacCoef<T> jk;
         jac_coef(c, r, jk);
@@ -285,7 +294,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             NMPC_WSYNC();
             NMPC_STAMP(4)
         }
-    }
+    };
+    if (c.steps <= 2) prepare(std::integral_constant<int, 2>{}); else prepare(std::integral_constant<int, AS_MAX_STEPS>{});
     __syncthreads();          // stage matrices (LDS, or this wave's own global rows) visible to every lane
     NMPC_STAMP(7)
 

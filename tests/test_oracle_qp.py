@@ -4,7 +4,7 @@ import pytest
 
 from oracle import oracle as O
 from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, sample_x0
-from tests.qp_check import solve_exact
+from tests.exact_qp import solve_exact
 
 NX, NU = 13, 4
 
@@ -272,3 +272,141 @@ def test_config5_block_120_condensing_agrees_with_the_uncondensed_qp():
     np.testing.assert_allclose(rc["u"], ru["u"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(rc["x"], ru["x"], rtol=0, atol=1e-6)
     assert tc > 5 * tu, (tc, tu)
+
+
+# ---------------------------------------------------------------- accuracy certificate, step test, U10 switch
+def _draw_instance(seed, inst):
+    from tests.fuzz_draws import draw, oracle_config
+    over, x0, yref, ye, hov, _, _ = draw(seed, materialise_refs=True)
+    return oracle_config(over), x0[inst], yref[inst], ye[inst], hov
+
+
+def test_growth_certificate_refuses_the_active_set_solve_it_cannot_trust():
+    """Draw 161 of the fuzz (rho(A) = 1.5, N = 40, 156 of 160 inputs saturated): the pinned Riccati recursion runs open loop
+    over most of the horizon, P grows by 1e12 and the FP64 active-set solve - on the RIGHT active set - is off by 2e-2 (against
+    a 60-digit solve of the same pinned problem, tools/dev history in DESIGN.md section 2).  With the certificate the pass is
+    not accepted and the interior-point iteration is stopped where its own factorisations stop being trusted: QP failure,
+    the command is discarded (controller.py:448-450).  Without it both paths report success and differ by 1e-2."""
+    c, x0, yref, ye, hov = _draw_instance(161, 28)
+    N = c.N
+    res = {}
+    for gmax in (1e6, 0.0):
+        for polish in (1, 0):
+            c.qp_growth_max, c.qp_polish = gmax, polish
+            s, xn, un, st = O.sqp_rti(c, x0, yref, ye, np.tile(x0, (N + 1, 1)), np.zeros((N, NU)))
+            res[gmax, polish] = (s, un[0].copy(), st)
+    assert res[1e6, 1][0] == 4 and res[1e6, 0][0] == 4
+    assert res[1e6, 1][2].untrusted == 1 and res[1e6, 1][2].growth > 1e6
+    assert res[0.0, 1][0] == 0 and res[0.0, 0][0] == 0 and res[0.0, 1][2].polished == 1
+    assert np.abs(res[0.0, 1][1] - res[0.0, 0][1]).max() > 1e-3          # "exact" active-set answer vs converged interior point
+    # an ordinary instance of the same draw is untouched by the certificate
+    c, x0, yref, ye, hov = _draw_instance(161, 7)
+    c.qp_polish = 1
+    s, xn, un, st = O.sqp_rti(c, x0, yref, ye, np.tile(x0, (N + 1, 1)), np.zeros((N, NU)))
+    assert s == 0 and st.polished == 1 and st.untrusted == 0 and st.growth < 1e2
+
+
+def test_reference_vehicle_never_comes_near_the_growth_cap():
+    c = O.default_config(qp_polish=1)
+    yref, ye = O.hover_yref(c)
+    for dist, seed in ((NEAR_HOVER, 0), (AGGRESSIVE, 1), (WILD, 2)):
+        r = O.solve_batch(c, sample_x0(64, seed, **dist), yref, ye)
+        assert (r["status"] == 0).all() and r["growth"].max() < 10.0
+
+
+def test_accepted_active_set_has_multipliers_of_the_right_sign_in_extended_precision():
+    """The multiplier check of an active-set pass uses the costate P x + p of the pinned problem.  On the unstable plant of
+    tests/test_gpu_parity.py (rho(A) = 2) at N = 120 the adjoint recursion it replaced amplified rounding by 2^k and accepted
+    instance 123 with a multiplier of the wrong sign by 8e-2.  Independent check: the pinned LQ problem of the accepted active
+    set solved in 80-bit arithmetic, multipliers by the adjoint recursion in that precision."""
+    from rotors_mpc_controller_amd import _lib
+    from tests.fuzz_draws import oracle_config
+    N = 120
+    over = dict(N=N, dt=0.1, mass=0.4738978976479069, inertia=[0.0017, 0.006, 0.012],
+                rotor_x=[0.4541, 0.0, -0.4541, 0.0], rotor_y=[0.0, 0.4541, 0.0, -0.4541], rotor_z=[-0.0141, 0.0141, -0.0141, 0.0141],
+                lbu=[0.0452] * 4, ubu=[2.0395] * 4,
+                W=[0.1868, 4.7625, 0.1212, 70.9006, 3.7842, 57.0244, 0.0357, 32.6734, 12.5504, 0.1446, 29.7859, 5.8384, 0.409,
+                   11.6702, 0.8986, 3.7607, 0.0134],
+                W_e=[0.127, 13.7797, 13.6895, 2.7246, 3.6848, 4.8743, 0.2726, 140.7136, 0.5401, 23.0029, 17.7842, 0.149, 23.2557],
+                levenberg_marquardt=0.0, sim_num_steps=1, lm_scaled_by_dt=1, cost_scaled_by_dt=1, flags=_lib.FLAG_TEAM_MAPPING)
+    c = oracle_config(over, qp_polish=1)
+    x0 = sample_x0(511, 9021, **WILD)[123]
+    hov = over["mass"] * 9.81 / 4.0
+    yref = np.zeros((N, 17)); yref[:, 2] = 1.0; yref[:, 6] = 1.0; yref[:, 13:] = hov
+    ye = yref[0, :13].copy()
+    xt, ut = np.tile(x0, (N + 1, 1)), np.zeros((N, NU))
+    s, xn, un, st = O.sqp_rti(c, x0, yref, ye, xt, ut)
+    assert s == 0 and st.polished == 1
+    qp = O.linearize(c, xt, ut, yref, ye)
+    du = un - ut
+    w = qp["hi"] - qp["lo"]
+    pins = np.where(du - qp["lo"] < 1e-9 * w, -1, np.where(qp["hi"] - du < 1e-9 * w, 1, 0))
+    L = np.longdouble
+    f = lambda a: np.asarray(a, dtype=L)
+    P, p, gains = np.diag(f(qp["Qd"][N])), f(qp["q"][N]), []
+    for k in range(N - 1, -1, -1):              # Riccati recursion of the pinned problem, Gauss-Jordan on H (SPD)
+        A, B, b = f(qp["A"][k]), f(qp["B"][k]), f(qp["b"][k])
+        free = [i for i in range(NU) if pins[k][i] == 0]
+        v = f([0.0 if pins[k][i] == 0 else (qp["lo"][k][i] if pins[k][i] < 0 else qp["hi"][k][i]) for i in range(NU)])
+        bk, Bk = b + B @ v, B[:, free]
+        h = P @ bk + p
+        K, kk = np.zeros((0, NX), L), np.zeros(0, L)
+        Pn, pn = np.diag(f(qp["Qd"][k])) + A.T @ P @ A, f(qp["q"][k]) + A.T @ h
+        if free:
+            n = len(free)
+            Mx = np.concatenate([np.diag(f(qp["Rd"][k])[free]) + Bk.T @ P @ Bk, Bk.T @ P @ A, (f(qp["r"][k])[free] + Bk.T @ h)[:, None]], axis=1)
+            for cc in range(n):
+                Mx[cc] = Mx[cc] / Mx[cc, cc]
+                for rr in range(n):
+                    if rr != cc:
+                        Mx[rr] = Mx[rr] - Mx[rr, cc] * Mx[cc]
+            K, kk = -Mx[:, n:n + NX], -Mx[:, n + NX]
+            G = Bk.T @ P @ A
+            Pn, pn = Pn + G.T @ K, pn + G.T @ kk
+        gains.append((free, v, K, kk))
+        P, p = (Pn + Pn.T) / 2, pn
+    x, us, xs = np.zeros(NX, L), np.zeros((N, NU), L), [np.zeros(NX, L)]
+    for k, (free, v, K, kk) in enumerate(reversed(gains)):
+        u = v.copy()
+        if free:
+            u[free] = K @ x + kk
+        us[k] = u
+        x = f(qp["A"][k]) @ x + f(qp["B"][k]) @ u + f(qp["b"][k])
+        xs.append(x)
+    assert np.abs(np.asarray(us, float) - du).max() < 1e-9          # the oracle's answer is the solution on its active set ...
+    pi = f(qp["Qd"][N]) * xs[N] + f(qp["q"][N])
+    worst = 0.0
+    for k in range(N - 1, -1, -1):                                  # ... and that set is the optimal one
+        g = f(qp["Rd"][k]) * us[k] + f(qp["r"][k]) + f(qp["B"][k]).T @ pi
+        for i in range(NU):
+            if pins[k][i] < 0: worst = max(worst, float(-g[i]))
+            elif pins[k][i] > 0: worst = max(worst, float(g[i]))
+            else: assert qp["lo"][k][i] - 1e-9 <= us[k][i] <= qp["hi"][k][i] + 1e-9
+        pi = f(qp["Qd"][k]) * xs[k] + f(qp["q"][k]) + f(qp["A"][k]).T @ pi
+    assert worst < 1e-6, worst
+
+
+def test_U10_switch_reports_or_tolerates_the_qp_iteration_cap():
+    c = O.default_config(qp_iter_max=1)
+    yref, ye = O.hover_yref(c)
+    x0 = sample_x0(4, 1, **AGGRESSIVE)
+    tol = O.solve_batch(c, x0, yref, ye, want_traj=True)
+    c.qp_maxiter_status = 2
+    rep = O.solve_batch(c, x0, yref, ye, want_traj=True)
+    assert (tol["status"] == 0).all() and (tol["iters"] == 1).all() and np.abs(tol["u0"]).min() > 0
+    assert (rep["status"] == 2).all() and (rep["u0"] == 0).all()          # controller.py:448-450: command discarded ...
+    assert np.array_equal(rep["x"], np.tile(x0[:, None, :], (1, c.N + 1, 1)))   # ... and the warm start invalidated
+
+
+def test_step_test_keeps_iterating_while_the_last_step_is_large():
+    """qp_tol_step: mu and the tracked stationarity factor alone would stop; a last step of a sizeable fraction of the box
+    width means the iterate has not settled."""
+    c = O.default_config(qp_tol_comp=1e-2, qp_tol_stat=1.0, qp_tol_step=0.0)
+    yref, ye = O.hover_yref(c)
+    x0 = sample_x0(16, 1, **AGGRESSIVE)
+    loose = O.solve_batch(c, x0, yref, ye)
+    c.qp_tol_step = 1e-6
+    tight = O.solve_batch(c, x0, yref, ye)
+    assert (tight["iters"] >= loose["iters"]).all() and (tight["iters"] > loose["iters"]).any()
+    exact = O.solve_batch(O.default_config(qp_polish=1), x0, yref, ye)
+    assert np.abs(tight["u0"] - exact["u0"]).max() < np.abs(loose["u0"] - exact["u0"]).max()

@@ -50,6 +50,9 @@ run("plain ipm N=5 wild", dict(qp_polish=0), dict(qp_polish=0), WILD, 3, N=5)
 run("plain ipm N=57 wild", dict(qp_polish=0), dict(qp_polish=0), WILD, 4, N=57)
 run("default N=57 wild", dict(), dict(qp_polish=1), WILD, 4, N=57, warm=True)
 run("attempt after ipm (pol_mu 1e-2)", dict(qp_polish_mu=1e-2), dict(qp_polish=1, qp_polish_mu=1e-2), AGGRESSIVE, 5)
+run("3 integrator steps, default", dict(sim_num_steps=3), dict(qp_polish=1, sim_num_steps=3), WILD, 7, warm=True)
+run("4 integrator steps, plain ipm", dict(sim_num_steps=4, qp_polish=0, flags=_lib.FLAG_TEAM_MAPPING), dict(qp_polish=0, sim_num_steps=4), AGGRESSIVE, 8, warm=True)
+run("3 integrator steps, shared N=57", dict(sim_num_steps=3), dict(qp_polish=1, sim_num_steps=3), AGGRESSIVE, 9, N=57, warm=True)
 run("iter cap 3, reported", dict(qp_polish=0, qp_iter_max=3, qp_maxiter_status=2), dict(qp_polish=0, qp_iter_max=3, qp_maxiter_status=2), NEAR_HOVER, 6)
 run("iter cap 3, tolerated", dict(qp_polish=0, qp_iter_max=3), dict(qp_polish=0, qp_iter_max=3), NEAR_HOVER, 6)
 print("worst |du0| over all rows: %.2e" % worst)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Large-sample parity sweep of the GPU path against the CPU oracle (run by hand on the GPU box:
-`python tests/stress_parity.py`).  Not collected by pytest: the unit tests hold the same bar on
+`python tools/stress_parity.py`).  Not collected by pytest: the unit tests hold the same bar on
 smaller samples.  Cold start and one warm-started second iteration, three input distributions,
 several seeds, shared and per-stage linearisation."""
 import sys
