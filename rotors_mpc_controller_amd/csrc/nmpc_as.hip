@@ -1,5 +1,6 @@
-// nmpc_as.hip -- the active-set kernels of the default FP64 path and their launcher (see nmpc_as_launch.hpp for why this
-// is a translation unit of its own).
+// nmpc_as.hip -- k_team_as, the active-set kernel of the default FP64 path, built with -mllvm -amdgpu-mfma-vgpr-form (see
+// nmpc_as_launch.hpp for why this is a translation unit of its own; every other kernel of nmpc_team_as.hpp lives in nmpc_qp.hip,
+// built WITHOUT that flag).
 #include <hip/hip_runtime.h>
 
 #include "nmpc_as_launch.hpp"
@@ -21,57 +22,9 @@ __global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__res
     team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off);
 }
 
-// The whole QP of every instance of the batch in one launch (team_as MODE 1): interior-point iterations in the tile form,
-// active-set attempts in between when qp_polish is on.  What qp_polish = 0 runs, and NMPC_TEAM_SPLIT=0.  One wave per SIMD.
-template <bool SHARED, bool TRAJ, class TI>
-__global__ __launch_bounds__(64, 1) void k_team_qp(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
-                                                   TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg, int lm_off)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    team_as<SHARED, TRAJ, true, TI, 1>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off);
-}
-
-// Second launch of the default FP64 path (team_as MODE 2): the instances the active-set kernel appended to the work list -
-// usually none - continue where its first attempt ended: interior-point iterations, further attempts from the iterate's
-// active-set guess.  A fixed small grid strides over the list; the last workgroup to finish resets it for the next solve.
-template <bool SHARED, bool TRAJ, class TI>
-__global__ __launch_bounds__(64, 1) void k_team_qp_list(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
-                                                        TeamWork<double> tw, WorkList wl, int B, int lds_stride, int lstg, int lm_off)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const int n = *wl.count;
-    const int team = (threadIdx.x >> 2) & 3;
-    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
-        const int e = base + team;
-        const int inst = e < n ? wl.list[e] : -1;
-        team_as<SHARED, TRAJ, true, TI, 2>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, inst);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(wl.done, 1);          // every workgroup has read the count before it arrives here
-        if (t == (int)gridDim.x - 1) { *wl.count = 0; *wl.done = 0; }
-    }
-}
-
 template <class TI>
 int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 {
-    if (a.kind == 1) {
-        const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
-#define NMPC_LAUNCH_QP(SH_, TR_) hipLaunchKernelGGL((k_team_qp<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off)
-        if (a.shared) { if (a.traj) NMPC_LAUNCH_QP(true, true); else NMPC_LAUNCH_QP(true, false); }
-        else { if (a.traj) NMPC_LAUNCH_QP(false, true); else NMPC_LAUNCH_QP(false, false); }
-#undef NMPC_LAUNCH_QP
-        return (int)hipGetLastError();
-    }
-    if (a.kind == 2) {
-        const dim3 grid(a.nlist), block(64);
-#define NMPC_LAUNCH_QL(SH_, TR_) hipLaunchKernelGGL((k_team_qp_list<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.lds_stride, a.lstg, a.lm_off)
-        if (a.shared) { if (a.traj) NMPC_LAUNCH_QL(true, true); else NMPC_LAUNCH_QL(true, false); }
-        else { if (a.traj) NMPC_LAUNCH_QL(false, true); else NMPC_LAUNCH_QL(false, false); }
-#undef NMPC_LAUNCH_QL
-        return (int)hipGetLastError();
-    }
     const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
 #define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off)
     if (a.shared) {

@@ -1,8 +1,7 @@
-// nmpc_as_launch.hpp -- host-side hand-over between the C ABI (nmpc_capi.hip) and the translation unit that holds the
-// active-set kernels (nmpc_as.hip).  The two are compiled separately because the active-set kernels are built with
-// -mllvm -amdgpu-mfma-vgpr-form (MFMA results in the vector registers the following VALU reads: +9 % on them), a flag
-// under which this compiler miscounts the interior-point iterations of the general kernel (results stay right; found by
-// the iteration statistics of the plain-IPM parity run), so the general kernels keep the default code generation.
+// nmpc_as_launch.hpp -- host-side hand-over between the C ABI (nmpc_capi.hip) and the two translation units that hold the kernels of
+// nmpc_team_as.hpp: nmpc_as.hip (k_team_as built with -mllvm -amdgpu-mfma-vgpr-form: MFMA results in the vector registers the
+// following VALU reads, +9 % on that kernel) and nmpc_qp.hip (everything else, default code generation - the flag miscompiles
+// other instantiations, see nmpc_qp.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -25,8 +24,11 @@ struct AsLaunch {
     hipStream_t stream;
 };
 
-// enqueue k_team_as<shared, traj, occ, TI> / k_team_qp / k_team_qp_list (kind); returns a hipError_t
+// enqueue k_team_as<shared, traj, occ, TI> of nmpc_as.hip (kind 0 only); returns a hipError_t
 int launch_team_as(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
 int launch_team_as(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
+// enqueue a kernel of nmpc_qp.hip: k_team_as (kind 0), k_team_qp (1), k_team_qp_list (2)
+int launch_team_qp(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
+int launch_team_qp(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
 
 }  // namespace nmpc

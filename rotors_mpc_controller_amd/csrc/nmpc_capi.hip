@@ -118,6 +118,7 @@ struct nmpc_solver {
     double *d_gbase = nullptr;       // growth certificate: first-factorisation value per instance (active-set kernel -> work-list launch)
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
+    int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
     int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
@@ -323,6 +324,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
@@ -426,13 +428,15 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
     al.lds_stride = lds_stride; al.lstg = lstg; al.lm_off = base_as; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
     al.lds_bytes = lds_as; al.stream = st;
-    HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
+    // k_team_as: the flag build (nmpc_as.hip) for what it is validated on, the default-codegen build (nmpc_qp.hip) otherwise
+    if (s->cfg.sim_num_steps <= 2 && !s->as_noflag) HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
+    else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
     if (s->team_qp) {
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1;
-        HIP_TRY(s, (hipError_t)launch_team_as(ql, in, out));
+        HIP_TRY(s, (hipError_t)launch_team_qp(ql, in, out));
     } else {
         if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
         else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
@@ -554,7 +558,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                 al.occ = 1; al.shared = c.shared != 0; al.traj = out.x_out != nullptr || out.u_out != nullptr;
                 al.stream = st; al.kind = 1;
                 qp_lds(s, c.shared != 0, al);
-                HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
+                HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
                 if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
                 s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
                 return 0;

@@ -754,15 +754,23 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             if (kl > 0) {
                 Ops ol;
                 T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
-                T n_u = 0, n_ll = 0, n_lu = 0;
-                if (IPMV) { n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta]; }
+                T n_u = 0, n_ll = 0, n_lu = 0, m_u = 0, m_ll = 0, m_lu = 0;      // interior-point variant: the iterate two stages ahead
+                if (IPMV) {
+                    n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta];
+                    const T *iv1 = tIV + (1 < N ? 1 : 0) * IV_ROWS;
+                    m_u = iv1[ta]; m_ll = iv1[4 + ta]; m_lu = iv1[8 + ta];
+                }
                 fetch_ops_lds(0, ol);
                 for (int k = 0; k < kl; k++) {
                     ol.ul = n_ul; ol.pc = n_pc; ol.u = n_u; ol.ll = n_ll; ol.lu = n_lu;
                     const int kn = k + 1 < N ? k + 1 : k;
                     n_ul = ulin(kn, ta);
                     if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
-                    if (IPMV) { const T *ivn = tIV + kn * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
+                    if (IPMV) {
+                        n_u = m_u; n_ll = m_ll; n_lu = m_lu;
+                        const T *ivn = tIV + (k + 2 < N ? k + 2 : N - 1) * IV_ROWS;
+                        m_u = ivn[ta]; m_ll = ivn[4 + ta]; m_lu = ivn[8 + ta];
+                    }
                     stageB(k, ol);
                     if (k + 1 < kl) fetch_ops_lds(k + 1, ol);
                 }
@@ -895,12 +903,14 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         }
         if constexpr (LDSC) {
             if (kl > 0) {
-                OpsD ol, on;
+                OpsD ol, on, on2;                          // scalars two stages ahead, as in sweep E
                 fetch_sc(kl - 1, on);
+                fetch_sc(kl - 2, on2);
                 for (int k = kl - 1; k >= 0; k--) {
                     fetch_d_lds(k, ol);
                     ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
-                    fetch_sc(k - 1, on);
+                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
+                    fetch_sc(k - 2, on2);
                     stageD(k, ol, Tr{});
                 }
             }
@@ -982,12 +992,15 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         NMPC_UNROLL for (int i = 0; i < H; i++) fetch_e(kb + i, oa[i]);
         if constexpr (LDSC && SHARED) {
             if (kl > 0) {
-                OpsE ol, on;
+                // the iterate's scalars come from global memory two stages ahead (a stage is shorter than an L2 round trip)
+                OpsE ol, on, on2;
                 fetch_sc(0, on);
+                fetch_sc(1 < N ? 1 : 0, on2);
                 fetch_e_lds(0, ol);
                 for (int k = 0; k < kl; k++) {
                     ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
-                    fetch_sc(k + 1 < N ? k + 1 : k, on);
+                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
+                    fetch_sc(k + 2 < N ? k + 2 : N - 1, on2);
                     stageE(k, ol);
                     if (k + 1 < kl) fetch_e_lds(k + 1, ol);
                 }
@@ -1004,35 +1017,37 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     // ================= sweep F: primal-dual update, duality measure of the new iterate, active-set guess for a later attempt
     T msF = 0;
     auto sweepF = [&](T alpha) {
+        // element-wise: lane (a,c) takes input a of the stages k = c, c + 4, c + 8, ... (every lane works: four stages per
+        // instruction instead of one replicated four times - the sweep is all FP64 vector arithmetic)
         T ms = 0;
-        constexpr int CHF = 10;
-        const int us = tc == 0 ? ta : 20 + ta, ls = tc == 0 ? 4 + ta : 20 + ta, hs = tc == 0 ? 8 + ta : 20 + ta, ps = tc == 0 ? 16 + ta : 20 + ta;
-        for (int k0 = 0; k0 < N; k0 += CHF) {
+        constexpr int CHF = 5;
+        for (int k0 = 0; k0 < N; k0 += 4 * CHF) {
             T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_ua[CHF], f_d[CHF];
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
-                const int k = (k0 + i < N) ? k0 + i : N - 1;
+                const int kq = k0 + 4 * i + tc;
+                const int k = kq < N ? kq : N - 1;
                 const T *ivn = tIV + k * IV_ROWS;
                 f_ul[i] = ulin(k, ta);
                 f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
             }
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
-                const int k = k0 + i;
-                if (k < N) {
-                    T *ivk = tIV + k * IV_ROWS;
-                    T u = f_u[i], ll = f_ll[i], lu = f_lu[i];
-                    const T lo = lb_a - f_ul[i], hi = ub_a - f_ul[i];
-                    const Pair<T> pr(u, ll, lu, lo, hi);
-                    const T da = f_ua[i] - u, d = f_d[i];
-                    const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
-                    const T cl = dla * da, cu = -dua * da;
-                    const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
-                    const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
-                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
-                    ivk[us] = u; ivk[ls] = ll; ivk[hs] = lu;
-                    // active-set guess for a later attempt: a bound whose multiplier exceeds its slack
-                    ivk[ps] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
-                    ms += ll * (u - lo) + lu * (hi - u);
-                }
+                const int kq = k0 + 4 * i + tc;
+                const bool live = kq < N;
+                // a lane past the horizon repeats stage N - 1 into the spare slots of that stage
+                T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
+                T u = f_u[i], ll = f_ll[i], lu = f_lu[i];
+                const T lo = lb_a - f_ul[i], hi = ub_a - f_ul[i];
+                const Pair<T> pr(u, ll, lu, lo, hi);
+                const T da = f_ua[i] - u, d = f_d[i];
+                const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
+                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                u += alpha * d; ll += alpha * dl; lu += alpha * du;
+                ivk[live ? ta : 20 + ta] = u; ivk[live ? 4 + ta : 20 + ta] = ll; ivk[live ? 8 + ta : 20 + ta] = lu;
+                // active-set guess for a later attempt: a bound whose multiplier exceeds its slack
+                ivk[live ? 16 + ta : 20 + ta] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
+                ms += live ? ll * (u - lo) + lu * (hi - u) : T(0);
             }
         }
         msF = ms;
@@ -1245,9 +1260,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const T alpha = c.tau / rmx;
                 sweepF(alpha);
                 NMPC_STAMP(4)
-                if (tc == 0) sRed[16 + ta] = msF;
+                sh[r] = msF;
                 __syncthreads();
-                const T ms = sRed[16] + sRed[17] + sRed[18] + sRed[19];
+                T ms = 0;
+                NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
                 if (ipm2) {
                     if (!(alpha == alpha)) { status = 1; mode = M_DONE; }
                     else if (alpha < T(1e-12)) { status = 3; mode = M_DONE; }

@@ -481,3 +481,28 @@ def test_plain_ipm_iteration_counts_match_oracle():
     st = s.stats()
     assert st["iter_max"] == ref["iters"].max() and abs(st["iter_mean"] - ref["iters"].mean()) < 0.02
     assert (host == ref["iters"]).mean() > 0.97          # (a rounding-level difference may move a stopping test by one step)
+
+
+@pytest.mark.parametrize("share", [1, 0])
+def test_flag_build_of_the_active_set_kernel_is_bit_equal_to_the_default_codegen_build(share, monkeypatch):
+    """k_team_as is the one kernel built with -mllvm -amdgpu-mfma-vgpr-form (nmpc_as.hip): an internal compiler option that
+    miscompiled other instantiations of the same sources (nmpc_qp.hip has the story).  The same kernel is also built with the
+    default code generation; NMPC_AS_NOFLAG=1 selects that build.  Same arithmetic, different register placement: every output
+    bit must agree - cold, warm-started, trajectories, pass statistics."""
+    yref, ye = hover(_lib.default_config())
+    x0 = np.concatenate([sample_x0(200, 81, **NEAR_HOVER), sample_x0(200, 82, **AGGRESSIVE), sample_x0(111, 83, **WILD)])
+    res = []
+    for noflag in ("0", "1"):
+        monkeypatch.setenv("NMPC_AS_NOFLAG", noflag)
+        s = make_solver(flags=_lib.FLAG_TEAM_MAPPING | share)
+        a = s.solve_batch(x0, yref, ye, want_traj=True)
+        pa = s.passes()
+        b = s.solve_batch(x0, yref, ye, x_init=a["x"], u_init=a["u"], want_traj=True)
+        res.append((a, pa, b, s.passes()))
+        s.close()
+    (a0, p0, b0, q0), (a1, p1, b1, q1) = res
+    for key in ("u0", "status", "x", "u"):
+        np.testing.assert_array_equal(a0[key], a1[key])
+        np.testing.assert_array_equal(b0[key], b1[key])
+    np.testing.assert_array_equal(p0, p1)
+    np.testing.assert_array_equal(q0, q1)
