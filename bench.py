@@ -57,9 +57,15 @@ def executed_flops(N: int, n_ipm: float, n_pass: float, shared: bool) -> float:
 
 
 def cpu_baseline(B_sample: int, N: int):
-    """The CPU oracle (a port, not acados) on this box's host cores, bounded sample."""
+    """Two CPU restatements on this box's host cores, bounded samples of the config-2 instances (seed 0):
+    (1) the oracle (oracle/nmpc_oracle.c): dense, unstructured, readable - the parity checker, same algorithm as the GPU default
+        (active-set passes + interior point);
+    (2) the structured host build of the lane kernels' own bodies (tests/hostsim: sparse model Jacobians, packed Riccati
+        recursion on the 7 dense columns of A, no dense 13x13 loops) - plain interior point, the algorithm class HPIPM runs.
+    Both are ports (`kind`), neither is acados: the reference's own CPU path cannot be built here."""
     from oracle import oracle as O
-    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, sample_x0
+    from rotors_mpc_controller_amd import _lib
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
     c = O.default_config(N=N, qp_gamma=0.0, qp_polish=1)      # same algorithm as the GPU default
     yref, ye = O.hover_yref(c)
     x0 = sample_x0(B_sample, 0, **NEAR_HOVER)
@@ -72,19 +78,43 @@ def cpu_baseline(B_sample: int, N: int):
     t = time.perf_counter()
     O.solve_batch(c, x0[:n1], yref, ye, nthreads=1)
     dt_1 = time.perf_counter() - t
-    return out, dict(value=B_sample / dt_all, unit="solves/s", cores=cores, kind="port",
-                     sample=f"{B_sample} of the config-2 instances (seed 0), OpenMP over instances, "
-                            f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM)",
-                     single_thread_value=n1 / dt_1)
+    row = dict(value=B_sample / dt_all, unit="solves/s", cores=cores, kind="port",
+               sample=f"{B_sample} of the config-2 instances (seed 0), OpenMP over instances, "
+                      f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM)",
+               single_thread_value=n1 / dt_1)
+    try:
+        from tests import hostsim as H
+        cfg = _lib.default_config(N=N, flags=_lib.FLAG_SHARE_COLD_START)
+        yr, yre = hover_reference(N, cfg.mass * cfg.gravity / 4.0)
+        Bs = 4 * B_sample                                     # ~10x faster per solve than the oracle: a larger sample for a stable figure
+        xs = sample_x0(Bs, 0, **NEAR_HOVER)
+        chk = H.solve_batch(cfg, x0, yr, yre, nthreads=cores)            # warm-up = the check: the oracle's own sample
+        t = time.perf_counter()
+        hs = H.solve_batch(cfg, xs, yr, yre, nthreads=cores)
+        ds_all = time.perf_counter() - t
+        n1 = max(256, Bs // max(cores, 1))
+        t = time.perf_counter()
+        H.solve_batch(cfg, xs[:n1], yr, yre, nthreads=1)
+        ds_1 = time.perf_counter() - t
+        ok = (chk["status"] == 0) & (out["status"] == 0)
+        row["structured"] = dict(value=Bs / ds_all, unit="solves/s", cores=cores, kind="port", single_thread_value=n1 / ds_1,
+                                 sample=f"{Bs} of the config-2 instances (seed 0), OpenMP over instances, host build of the lane kernel "
+                                        f"bodies nmpc_lane.hpp / nmpc_ipm.hpp (tests/hostsim): structured Riccati, plain interior point",
+                                 ipm_iterations_mean=float(hs["iters"].mean()),
+                                 max_abs_u0_vs_oracle=float(np.abs(chk["u0"][ok] - out["u0"][ok]).max()),
+                                 note="plain interior point to mu <= 1e-11 (no active-set shortcut: ~8x the factorisations of row 1 on this "
+                                      "workload); the difference to the oracle's exact active-set answer is the interior point's own accuracy")
+    except Exception as e:                                    # the baseline must never take the bench line down
+        row["structured"] = dict(error=f"{type(e).__name__}: {e}")
+    return out, row
 
 
 def source_hash() -> str:
-    """sha1 over the kernel sources: ties a committed PMC summary to the build it was captured on."""
-    h = hashlib.sha1()
-    for f in sorted((ROOT / "rotors_mpc_controller_amd" / "csrc").glob("*.h*")):
-        h.update(f.name.encode())
-        h.update(f.read_bytes())
-    return h.hexdigest()[:12]
+    """sha1 over the kernel sources (tools/source_hash.py): ties a committed PMC summary to the build it was captured on, and -
+    compared with the hash compiled into the loaded binary (nmpc_version()) - shows a stale .so."""
+    sys.path.insert(0, str(ROOT / "tools"))
+    from source_hash import source_hash as sh
+    return sh()
 
 
 def relaunch_under_torchrun(n: int) -> None:
@@ -403,7 +433,10 @@ def main() -> None:
             pmc = pmc_all.get(kname, {})
             # quoted only when the summary was captured on THIS build of the kernels (tools/summarize_pmc.py
             # records the hash of the kernel sources); otherwise null + a note, never a stale figure
-            if pmc_all.get("source_hash") != source_hash():
+            if _lib.library_source_hash() != source_hash():
+                traffic_note = (f"stale binary: librotors_nmpc_hip.so was built from kernel sources {_lib.library_source_hash()}, "
+                                f"the tree holds {source_hash()}")
+            elif pmc_all.get("source_hash") != source_hash():
                 traffic_note = f"stale profile: {pmc_file.name} was captured on kernel sources {pmc_all.get('source_hash')}, this build is {source_hash()}"
             elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
@@ -456,6 +489,8 @@ def main() -> None:
             line["max_abs_u0_vs_oracle"] = float(np.abs(u0_h[:ns][ok] - ref["u0"][ok]).max())
             line["parity_note"] = "vs build CPU oracle; acados parity unpinned (SURVEY 8c)"
         line["source_hash"] = source_hash()
+        line["binary_source_hash"] = _lib.library_source_hash()
+        line["library_version"] = _lib.load().nmpc_version().decode()
     # ---- rows measured AFTER the timed region (never part of `value`)
     if use_dist and G == 1 and not args.no_secondary:
         # the batched exchange: u0 of 8 consecutive ticks share one asynchronous all-gather

@@ -13,6 +13,11 @@
  * Threading: one handle = one thread at a time (the reference serialises solve and rebuild
  * with _controller_lock, nodes/mpc_controller_node:122,193).  All calls are synchronous at
  * the ABI except nmpc_solve_batch_device, which only enqueues on the given stream.
+ * One handle = one solve in flight: every solve uses the handle's single device workspace.  A caller that enqueues
+ * nmpc_solve_batch_device on a stream of its own must synchronise that stream before the next call on the same handle that may
+ * run elsewhere - another stream, or the host-buffer entry points nmpc_solve / nmpc_solve_batch, whose small-batch latency path
+ * (B <= 64) runs on a private non-blocking stream (it waits for the NULL stream by itself, not for user streams).  Independent
+ * batches in flight = independent handles (rotors_mpc_controller_amd/pipeline.py).
  */
 #ifndef ROTORS_NMPC_H
 #define ROTORS_NMPC_H
@@ -89,8 +94,8 @@ typedef struct nmpc_config {
      * (then the result is the exact QP solution); otherwise correct the active set (primal-dual
      * active-set step) or fall back to the interior point iteration.                                  */
     int32_t qp_polish;         /* 0 = plain IPM, 1 = on */
-    int32_t qp_polish_passes;  /* active-set corrections per attempt; 0 (default) = 8 */
-    int32_t qp_polish_budget;  /* no new attempt after this many passes; 0 (default) = 16 */
+    int32_t qp_polish_passes;  /* active-set corrections per attempt; default 8 (0 = the same) */
+    int32_t qp_polish_budget;  /* no new attempt after this many passes; default 16 (0 = the same) */
     double qp_polish_mu;       /* first attempt when mu <= this (>= mu0: before any IPM iteration), then every 100x below */
     int32_t qp_polish_ckpt;    /* leading stages whose Riccati state (P_k, p_k) a corrected active-set pass checkpoints
                                   (the first pass of an attempt keeps at most two): the next pass refactorises only
@@ -250,7 +255,13 @@ int nmpc_adjoint_sensitivities_device(nmpc_solver *s, int B, const void *x, cons
 int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void *u_traj, const void *yref, const void *yref_e,
                            int yref_bcast, void *res, void *hip_stream);
 
+/* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */
 const char *nmpc_version(void);
+
+/* sizeof(nmpc_config) and sizeof(nmpc_stats) of THIS binary (either pointer may be NULL); returns the ABI revision (3).  A
+ * binding compares them with its own mirror of the structs before the first nmpc_create / nmpc_get_stats: both structs grew in
+ * rounds 2 and 3, and nmpc_get_stats writes sizeof(nmpc_stats) bytes into the caller's buffer.                               */
+int nmpc_abi_sizes(int *config_bytes, int *stats_bytes);
 
 #ifdef __cplusplus
 }

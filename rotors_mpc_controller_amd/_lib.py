@@ -71,7 +71,7 @@ class NmpcStats(C.Structure):
 EXPORTS = (
     "nmpc_default_config", "nmpc_create", "nmpc_destroy", "nmpc_set", "nmpc_get", "nmpc_solve",
     "nmpc_solve_batch", "nmpc_solve_batch_device", "nmpc_device_iterations", "nmpc_device_passes", "nmpc_get_counts", "nmpc_get_stats", "nmpc_set_timing",
-    "nmpc_last_error", "nmpc_version", "nmpc_build_hover_reference_device",
+    "nmpc_last_error", "nmpc_version", "nmpc_abi_sizes", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
     "nmpc_hold_command_device", "nmpc_hold_and_step_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device",
 )
@@ -176,8 +176,21 @@ def load() -> C.CDLL:
     lib.nmpc_kkt_report_device.restype = C.c_int
     lib.nmpc_version.argtypes = []
     lib.nmpc_version.restype = C.c_char_p
+    lib.nmpc_abi_sizes.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    lib.nmpc_abi_sizes.restype = C.c_int
+    cb, sb = C.c_int(0), C.c_int(0)
+    lib.nmpc_abi_sizes(C.byref(cb), C.byref(sb))
+    if cb.value != C.sizeof(NmpcConfig) or sb.value != C.sizeof(NmpcStats):
+        raise RuntimeError(f"{path}: nmpc_config / nmpc_stats are {cb.value} / {sb.value} bytes in the library, "
+                           f"{C.sizeof(NmpcConfig)} / {C.sizeof(NmpcStats)} in this binding - rebuild (make -C {CSRC})")
     _lib = lib
     return lib
+
+
+def library_source_hash() -> str:
+    """Hash of the kernel sources the loaded binary was built from (the tail of nmpc_version())."""
+    v = load().nmpc_version().decode()
+    return v.rsplit("src ", 1)[1] if "src " in v else "unknown"
 
 
 def default_config(**over) -> NmpcConfig:

@@ -132,6 +132,7 @@ struct nmpc_solver {
     void *h_in = nullptr, *h_out = nullptr, *d_in = nullptr, *d_out = nullptr;
     size_t pack_in_bytes = 0, pack_out_bytes = 0;
     hipStream_t pack_stream = nullptr;
+    bool pack_ready = false;
     uint64_t ws_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start | after prepare | after the (first) solve kernel | after the work-list launch
     bool timed_split = false, last_split = false;
@@ -167,7 +168,19 @@ struct nmpc_solver {
 
 extern "C" {
 
-const char *nmpc_version(void) { return "rotors_nmpc_hip 0.1 (gfx950)"; }
+#ifndef NMPC_SOURCE_HASH
+#define NMPC_SOURCE_HASH "unknown"
+#endif
+// "rotors_nmpc_hip <abi> (gfx950) src <hash of the kernel sources this binary was built from>"
+const char *nmpc_version(void) { return "rotors_nmpc_hip 0.3 (gfx950) src " NMPC_SOURCE_HASH; }
+// sizes of the two public structs in THIS binary: a binding checks them against its own mirror before it trusts either
+// (nmpc_get_stats writes sizeof(nmpc_stats) bytes into the caller's buffer)
+int nmpc_abi_sizes(int *config_bytes, int *stats_bytes)
+{
+    if (config_bytes) *config_bytes = (int)sizeof(nmpc_config);
+    if (stats_bytes) *stats_bytes = (int)sizeof(nmpc_stats);
+    return 3;            // ABI revision: 3 = round 3 (qp_maxiter_status, certificate fields in nmpc_config; n_tail / ms_tail in nmpc_stats)
+}
 
 void nmpc_default_config(nmpc_config *c)
 {
@@ -209,8 +222,8 @@ void nmpc_default_config(nmpc_config *c)
     c->max_batch = 4096;
     c->flags = NMPC_FLAG_SHARE_COLD_START | NMPC_FLAG_TEAM_MAPPING;
     c->qp_polish = 1;
-    c->qp_polish_passes = 0;   // 0 = the measured default (nmpc_create): 8 passes per attempt, 16 in total
-    c->qp_polish_budget = 0;
+    c->qp_polish_passes = 8;   // the measured default (nmpc_create): 8 passes per attempt, 16 in total; 0 means the same
+    c->qp_polish_budget = 16;
     c->qp_polish_mu = 1.0;
     c->qp_polish_ckpt = 12;
     c->qp_maxiter_status = 0;
@@ -674,16 +687,31 @@ static int solve_packed(nmpc_solver *s, int B, const double *x0, const double *y
                         int32_t *status, double *x_out, double *u_out)
 {
     const size_t N = (size_t)s->cfg.N, e = s->esz, P = nmpc_solver::PACK_B;
-    if (!s->h_in) {
+    if (!s->pack_ready) {
+        // all five resources or none: a partial failure frees what it got, so that the next call starts over
         const size_t nin = P * (NX + N * NY + NX + (N + 1) * NX + N * NU), nout = P * (NU + (N + 1) * NX + N * NU);
         s->pack_in_bytes = nin * e;
         s->pack_out_bytes = nout * e + P * sizeof(int32_t) + 8;
-        HIP_TRY(s, hipStreamCreateWithFlags(&s->pack_stream, hipStreamNonBlocking));
-        HIP_TRY(s, hipHostMalloc(&s->h_in, s->pack_in_bytes, hipHostMallocDefault));
-        HIP_TRY(s, hipHostMalloc(&s->h_out, s->pack_out_bytes, hipHostMallocDefault));
-        HIP_TRY(s, hipMalloc(&s->d_in, s->pack_in_bytes));
-        HIP_TRY(s, hipMalloc(&s->d_out, s->pack_out_bytes));
+        hipError_t pe = hipStreamCreateWithFlags(&s->pack_stream, hipStreamNonBlocking);
+        if (pe == hipSuccess) pe = hipHostMalloc(&s->h_in, s->pack_in_bytes, hipHostMallocDefault);
+        if (pe == hipSuccess) pe = hipHostMalloc(&s->h_out, s->pack_out_bytes, hipHostMallocDefault);
+        if (pe == hipSuccess) pe = hipMalloc(&s->d_in, s->pack_in_bytes);
+        if (pe == hipSuccess) pe = hipMalloc(&s->d_out, s->pack_out_bytes);
+        if (pe != hipSuccess) {
+            if (s->d_out) (void)hipFree(s->d_out);
+            if (s->d_in) (void)hipFree(s->d_in);
+            if (s->h_out) (void)hipHostFree(s->h_out);
+            if (s->h_in) (void)hipHostFree(s->h_in);
+            if (s->pack_stream) (void)hipStreamDestroy(s->pack_stream);
+            s->d_out = s->d_in = s->h_out = s->h_in = nullptr; s->pack_stream = nullptr;
+            return s->fail(NMPC_EHIP, "latency path: allocation failed: %s", hipGetErrorString(pe));
+        }
+        s->pack_ready = true;
     }
+    // the workspace is shared with nmpc_solve_batch_device: work the caller enqueued on other streams must have drained before
+    // this stream touches it (the header asks the caller to synchronise; this makes the common case - everything on the NULL
+    // stream or on one stream that was synchronised - safe without it)
+    HIP_TRY(s, hipStreamSynchronize(nullptr));
     const size_t Bs = (size_t)B, nyr = (yref_bcast ? 1 : Bs) * N * NY, nye = (yref_bcast ? 1 : Bs) * NX;
     const bool warm = x_init != nullptr;
     const size_t o_x0 = 0, o_yr = o_x0 + Bs * NX, o_ye = o_yr + nyr, o_xi = o_ye + nye, o_ui = o_xi + (warm ? Bs * (N + 1) * NX : 0),

@@ -23,7 +23,7 @@ def lib():
         deps = [_HERE / "hostsim.cpp"] + sorted((_ROOT / "rotors_mpc_controller_amd" / "csrc").glob("*.hpp"))
         if not so.exists() or any(d.stat().st_mtime > so.stat().st_mtime for d in deps):
             flags = (["-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer"]
-                     if san else ["-O2"])
+                     if san else ["-O2", "-fopenmp"])
             subprocess.check_call(["g++"] + flags + ["-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-o", str(so), str(_HERE / "hostsim.cpp")])
         _lib = C.CDLL(str(so))
@@ -31,6 +31,8 @@ def lib():
         _lib.hostsim_solve_batch.argtypes = [C.POINTER(NmpcConfig), C.c_int, dp, dp, dp, C.c_int, dp, dp,
                                              dp, ip, dp, dp, ip]
         _lib.hostsim_solve_batch.restype = C.c_int
+        _lib.hostsim_set_threads.argtypes = [C.c_int]
+        _lib.hostsim_set_threads.restype = None
         _lib.hostsim_adjoint.argtypes = [C.POINTER(NmpcConfig), C.c_int, dp, dp, dp, dp, C.c_int]
         _lib.hostsim_adjoint.restype = C.c_int
     return _lib
@@ -40,7 +42,10 @@ def _p(a, t=C.c_double):
     return None if a is None else a.ctypes.data_as(C.POINTER(t))
 
 
-def solve_batch(cfg: NmpcConfig, x0, yref, yref_e, x_init=None, u_init=None):
+def solve_batch(cfg: NmpcConfig, x0, yref, yref_e, x_init=None, u_init=None, nthreads: int = 0):
+    """nthreads > 0: OpenMP threads over the instances (default: the OpenMP runtime's choice)."""
+    if nthreads > 0:
+        lib().hostsim_set_threads(int(nthreads))
     x0 = np.ascontiguousarray(x0, dtype=np.float64)
     yref = np.ascontiguousarray(yref, dtype=np.float64)
     yref_e = np.ascontiguousarray(yref_e, dtype=np.float64)

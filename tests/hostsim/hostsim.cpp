@@ -4,6 +4,9 @@
 // kernel arithmetic against the oracle without a GPU.  It is NOT linked into, loaded by, or
 // reachable from the product library (librotors_nmpc_hip.so has no CPU path).
 #include <cstdint>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <cstring>
 #include <vector>
 
@@ -35,6 +38,8 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
     Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), it.data(), st.data(), nullptr, nullptr, nullptr};
     Inputs<T> in{hx0.data(), hy.data(), hye.data(), x_init ? hxi.data() : nullptr, x_init ? hui.data() : nullptr, bcast};
     Outputs<T> out{ou0.data(), oxo.data(), ouo.data()};
+    // (instances are independent; OpenMP over lanes is what bench.py's second cpu_baseline row times)
+#pragma omp parallel for schedule(dynamic, 16)
     for (int lane = 0; lane < B; lane++) lane_prepare(c, w, in, lane);
     if (g.flags & NMPC_FLAG_CONDENSED_QP) {
         CondWork<T> cw;
@@ -42,14 +47,25 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
         std::vector<T> cbuf((size_t)cond_layout(cw, g.N, N2) * Bp);
         cw.base = cbuf.data();
         cw.Bp = (int)Bp;
+#pragma omp parallel for schedule(dynamic, 16)
         for (int lane = 0; lane < B; lane++) lane_cond_ipm(c, w, cw, out, lane);
     } else {
+#pragma omp parallel for schedule(dynamic, 16)
         for (int lane = 0; lane < B; lane++) lane_ipm(c, w, out, lane);
     }
     for (size_t i = 0; i < ou0.size(); i++) u0[i] = ou0[i];
     if (x_out) for (size_t i = 0; i < oxo.size(); i++) x_out[i] = oxo[i];
     if (u_out) for (size_t i = 0; i < ouo.size(); i++) u_out[i] = ouo[i];
     for (int i = 0; i < B; i++) { if (status) status[i] = st[i]; if (iters) iters[i] = it[i]; }
+}
+
+extern "C" void hostsim_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 
 extern "C" int hostsim_solve_batch(const nmpc_config *g, int B, const double *x0, const double *yref,
