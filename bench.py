@@ -292,6 +292,19 @@ def main() -> None:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
+        # RCCL prints a version banner on STDOUT when its communicator comes up (the first collective): keep this process's stdout
+        # for the ONE JSON line of the contract - C-level writes go to stderr until the communicator exists
+        sys.stdout.flush()
+        _saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            _w = torch.zeros(1, device=dev)
+            dist.all_reduce(_w)
+            torch.cuda.synchronize(dev)
+        finally:
+            sys.stdout.flush()
+            os.dup2(_saved_stdout, 1)
+            os.close(_saved_stdout)
 
     B, N = args.batch, args.horizon
     tdt, npdt, esz = (torch.float64, np.float64, 8) if args.dtype == "f64" else (torch.float32, np.float32, 4)
@@ -326,54 +339,166 @@ def main() -> None:
     else:
         yref = torch.from_numpy(np.tile(yref_h, (B, 1, 1)).astype(npdt)).to(dev).contiguous()
         yref_e = torch.from_numpy(np.tile(yref_e_h, (B, 1)).astype(npdt)).to(dev).contiguous()
-    # Command buffers: G consecutive ticks fill one group [G][B][4]; a full group is gathered by ONE
-    # asynchronous RCCL all-gather (own stream) while the next group is being solved into the other
-    # buffer.  A 0.1 ms step is launch-bound on the host side of a collective (enqueue + bookkeeping cost
-    # about as much as the solve itself), so the u0 exchange is batched: fewer, larger collectives over
-    # the point-to-point xGMI links.  Every tick's u0 is gathered; --gather-every 1 restores one per tick.
+    # ---- the exchange of the commands (the only collective the path has: u0 [B,4] per rank and tick, 128 KiB in FP64).
+    # Default (--gather-every 1, one collective per tick - the honest closed-loop exchange): the solve writes its commands
+    # STRAIGHT into this rank's slot of the gather buffer [world][B][4] (in-place all-gather: no staging copy), and solve +
+    # all-gather are ONE stream's work, captured once into a HIP graph and replayed per tick - no cross-stream event between a
+    # tick's solve and its collective or between consecutive ticks (in round 2 those events broke the back-to-back dispatch of
+    # the solves and cost 30 % of the rate in the one-rank rehearsal).  If the RCCL build cannot be captured the same two
+    # operations are enqueued eagerly on the one stream (`exchange` in the JSON line says which ran).
+    # --gather-every G > 1: the batched variant of round 1/2 - the u0 of G consecutive ticks fill one group buffer that one
+    # ASYNCHRONOUS all-gather moves while the next group is solved into the other buffer.
     G = max(1, args.gather_every)
-    u0g = [torch.zeros(G, B, 4, dtype=tdt, device=dev) for _ in range(2)]
     status = torch.zeros(B, dtype=torch.int32, device=dev)
     xo = torch.zeros(B, N + 1, 13, dtype=tdt, device=dev) if args.traj_out else None
     uo = torch.zeros(B, N, 4, dtype=tdt, device=dev) if args.traj_out else None
-    gathered = [torch.zeros(world, G, B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
-    pending = [None, None]
     stream = torch.cuda.current_stream(dev)
     tick = [0]
     last = [0, 0]                                                # (group buffer, slot) of the latest solve
+    exchange = "none"
+    per_tick = use_dist and G == 1
+    if per_tick:
+        # two gather buffers, ticks alternate: while the collective of tick t moves buffer t % 2, the solve of tick t + 1 fills the
+        # other one.  Inside the graph that is a second capture stream (graph edges, no run-time events): the small RCCL kernel runs
+        # in the tail of the next solve, whose last waves leave most SIMDs idle anyway.
+        gat2 = [torch.zeros(world, B, 4, dtype=tdt, device=dev) for _ in range(2)]
+        u0g = [g_[rank].unsqueeze(0) for g_ in gat2]             # [1][B][4] views: this rank's slot of each gather buffer
+        gathered = [g_.unsqueeze(1) for g_ in gat2]              # [world][1][B][4]
+        pending = [None]
+        KT = max(2, 2 * (int(os.environ.get("NMPC_BENCH_GRAPH_TICKS", "8")) // 2))      # ticks per graph replay (even)
 
-    def flush(k):
-        pending[k] = dist.all_gather_into_tensor(gathered[k].view(world * G * B, 4), u0g[k].view(G * B, 4), async_op=True)
+        def solve_into(b, cuda_stream):
+            solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, gat2[b][rank].data_ptr(),
+                                      status_ptr=status.data_ptr(),
+                                      x_out_ptr=xo.data_ptr() if xo is not None else 0,
+                                      u_out_ptr=uo.data_ptr() if uo is not None else 0, stream=cuda_stream)
 
-    def step():
-        t = tick[0]
-        tick[0] += 1
-        k, slot = (t // G) & 1, t % G
-        if use_dist and slot == 0 and pending[k] is not None:
-            pending[k].wait()                                   # group k's previous gather must have drained
-            pending[k] = None
-        last[0], last[1] = k, slot
-        solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0g[k][slot].data_ptr(),
-                                  status_ptr=status.data_ptr(),
-                                  x_out_ptr=xo.data_ptr() if xo is not None else 0,
-                                  u_out_ptr=uo.data_ptr() if uo is not None else 0,
-                                  stream=stream.cuda_stream)
-        if use_dist and slot == G - 1:                          # RCCL over xGMI, asynchronous to the next group
-            flush(k)
+        def gather(b):
+            dist.all_gather_into_tensor(gat2[b].view(world * B, 4), gat2[b][rank])     # in place, on the current stream
 
-    def fence():
-        if use_dist:
-            t = tick[0]
-            if t % G != 0:                                      # a partly filled group: gather it as well
-                k = (t // G) & 1
-                flush(k)
-                tick[0] = (t // G + 1) * G
-            for k in (0, 1):
-                if pending[k] is not None:
-                    pending[k].wait()
-                    pending[k] = None
-            dist.barrier()
+        def tick_ops(b, cuda_stream):
+            solve_into(b, cuda_stream)
+            gather(b)
+
+        solver.set_timing(False)
+        for b in (0, 1):
+            tick_ops(b, stream.cuda_stream)                      # communicator set-up, code objects: before any capture
         torch.cuda.synchronize(dev)
+        graph, graph_ticks = None, 1
+        mode = os.environ.get("NMPC_BENCH_EXCHANGE", "pipelined")       # pipelined | serial | eager
+        if mode == "pipelined":
+            try:
+                sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+                sa.wait_stream(stream)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=sa):
+                    ev_g = [None, None]                          # completion of the latest gather of each buffer
+                    for t in range(KT):
+                        b = t & 1
+                        if ev_g[b] is not None:
+                            sa.wait_event(ev_g[b])               # buffer b is free again
+                        solve_into(b, sa.cuda_stream)
+                        ev_s = torch.cuda.Event()
+                        ev_s.record(sa)
+                        sb.wait_event(ev_s)
+                        with torch.cuda.stream(sb):
+                            gather(b)
+                            ev_g[b] = torch.cuda.Event()
+                            ev_g[b].record(sb)
+                    sa.wait_stream(sb)                           # join: the replay ends when every gather has landed
+                torch.cuda.synchronize(dev)
+                g_.replay()
+                torch.cuda.synchronize(dev)
+                graph, graph_ticks = g_, KT
+                exchange = (f"in-place all-gather per tick, {KT} ticks per HIP-graph replay: the collective of tick t beside the solve of "
+                            f"tick t + 1 (graph edges between two capture streams)")
+            except Exception as e:
+                exchange = f"(pipelined capture failed: {type(e).__name__}) "
+                torch.cuda.synchronize(dev)
+                mode = "serial"
+        if graph is None and mode == "serial":
+            try:
+                gs = torch.cuda.Stream(dev)
+                gs.wait_stream(stream)
+                g_ = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g_, stream=gs):
+                    tick_ops(0, torch.cuda.current_stream(dev).cuda_stream)
+                torch.cuda.synchronize(dev)
+                g_.replay()
+                torch.cuda.synchronize(dev)
+                graph, graph_ticks = g_, 1
+                exchange = (exchange if exchange != "none" else "") + "in-place all-gather per tick, solve + collective replayed from one HIP graph"
+            except Exception as e:                               # RCCL not capturable on this build: same operations, eager
+                exchange = f"in-place all-gather per tick, eager on one stream (graph capture failed: {type(e).__name__})"
+                torch.cuda.synchronize(dev)
+        if graph is None and not exchange.startswith("in-place"):
+            exchange = "in-place all-gather per tick, eager on one stream"
+        carry = [0]
+
+        def step():
+            # one tick; a replay of the pipelined graph covers graph_ticks of them (the timed step counts are multiples of it:
+            # a remainder is run as single eager ticks)
+            tick[0] += 1
+            if graph is not None and graph_ticks > 1:
+                carry[0] += 1
+                if carry[0] == graph_ticks:
+                    carry[0] = 0
+                    graph.replay()
+            elif graph is not None:
+                graph.replay()
+            else:
+                tick_ops(0, stream.cuda_stream)
+
+        def eager_step():
+            tick_ops(0, stream.cuda_stream)
+
+        def fence():
+            for _ in range(carry[0]):                            # ticks counted but not yet replayed
+                tick_ops(0, stream.cuda_stream)
+            carry[0] = 0
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+    else:
+        u0g = [torch.zeros(G, B, 4, dtype=tdt, device=dev) for _ in range(2)]
+        gathered = [torch.zeros(world, G, B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
+        pending = [None, None]
+        if use_dist:
+            exchange = f"asynchronous all-gather of {G} ticks' commands (RCCL's own stream)"
+
+        def flush(k):
+            pending[k] = dist.all_gather_into_tensor(gathered[k].view(world * G * B, 4), u0g[k].view(G * B, 4), async_op=True)
+
+        def step():
+            t = tick[0]
+            tick[0] += 1
+            k, slot = (t // G) & 1, t % G
+            if use_dist and slot == 0 and pending[k] is not None:
+                pending[k].wait()                                   # group k's previous gather must have drained
+                pending[k] = None
+            last[0], last[1] = k, slot
+            solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0g[k][slot].data_ptr(),
+                                      status_ptr=status.data_ptr(),
+                                      x_out_ptr=xo.data_ptr() if xo is not None else 0,
+                                      u_out_ptr=uo.data_ptr() if uo is not None else 0,
+                                      stream=stream.cuda_stream)
+            if use_dist and slot == G - 1:                          # RCCL over xGMI, asynchronous to the next group
+                flush(k)
+
+        eager_step = step
+
+        def fence():
+            if use_dist:
+                t = tick[0]
+                if t % G != 0:                                      # a partly filled group: gather it as well
+                    k = (t // G) & 1
+                    flush(k)
+                    tick[0] = (t // G + 1) * G
+                for k in (0, 1):
+                    if pending[k] is not None:
+                        pending[k].wait()
+                        pending[k] = None
+                dist.barrier()
+            torch.cuda.synchronize(dev)
 
     # the timed region carries bench.py's own two HIP events only; the library's per-solve events
     # (two more stream operations per step) are switched back on for one untimed step afterwards,
@@ -396,9 +521,9 @@ def main() -> None:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     solver.set_timing(True)
-    step()
+    eager_step()
     fence()
-    st = solver.stats()                                          # HIP events of one extra, untimed step
+    st = solver.stats()                                          # HIP events of one extra, untimed (eagerly launched) step
     u0_h = u0g[last[0]][last[1]].cpu().numpy().astype(np.float64)
     if use_dist:                                                 # the gathered block of this rank is its own u0
         g = gathered[last[0]][rank, last[1]].cpu().numpy().astype(np.float64)
@@ -477,7 +602,8 @@ def main() -> None:
                                          f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
                                 batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
                                 device_buffers=("f32" if args.dtype != "f64" else "f64"),
-                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks"),
+                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks",
+                                exchange=exchange),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
                     active_set_passes=dict(mean=st["polish_mean"], max=st["polish_max"], accepted=st["n_polished"]),
                     status_histogram=st["n_status"], roofline=roof)
@@ -520,6 +646,22 @@ def main() -> None:
         run8(n8)
         e8 = torch.tensor([time.perf_counter() - t8], dtype=torch.float64, device=dev)
         dist.all_reduce(e8, op=dist.ReduceOp.MAX)
+        # ... and no exchange at all: what the per-tick collective costs against it (same process, same buffers)
+        def run0(n):
+            for _ in range(n):
+                solver.solve_batch_device(B, x0.data_ptr(), yref.data_ptr(), yref_e.data_ptr(), bcast, u0g8[0][0].data_ptr(),
+                                          status_ptr=status.data_ptr(), stream=stream.cuda_stream)
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+        run0(16)
+        t0_ = time.perf_counter()
+        run0(n8)
+        e0 = torch.tensor([time.perf_counter() - t0_], dtype=torch.float64, device=dev)
+        dist.all_reduce(e0, op=dist.ReduceOp.MAX)
+        if rank == 0:
+            line.setdefault("secondary", {})["no_exchange"] = dict(
+                value=world * B / (float(e0.item()) / n8), unit="solves/s", ms_per_step=1e3 * float(e0.item()) / n8,
+                what="the same solves with no collective at all (upper bound for any exchange scheme)")
         if rank == 0:
             line.setdefault("secondary", {})["gather_every_8"] = dict(
                 value=world * B / (float(e8.item()) / n8), unit="solves/s", ms_per_step=1e3 * float(e8.item()) / n8,

@@ -133,3 +133,30 @@ def test_library_binds_one_hip_runtime_without_importing_torch():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True,
                        cwd=str(__import__('pathlib').Path(__file__).resolve().parent.parent))
     assert r.returncode == 0 and r.stdout.startswith("ok"), r.stderr + r.stdout
+
+
+def test_shell_helpers_parse():
+    """tools/*.sh are run on the GPU box only: at least their syntax is checked here (a trailing comment once swallowed a loop header)."""
+    import subprocess
+    from pathlib import Path
+    for sh in sorted((Path(__file__).resolve().parent.parent / "tools").glob("*.sh")):
+        assert subprocess.run(["bash", "-n", str(sh)], capture_output=True).returncode == 0, sh.name
+
+
+def test_binding_mirrors_the_structs_of_the_loaded_library():
+    """nmpc_abi_sizes: the ctypes mirrors of nmpc_config / nmpc_stats have the sizes the binary was compiled with (load() refuses a
+    mismatch), the version string carries the hash of the kernel sources the binary was built from, and - after build() - that is
+    the hash of the sources in the tree."""
+    import ctypes as C
+    import sys
+    from pathlib import Path
+    from rotors_mpc_controller_amd import _lib
+    lib = _lib.load()
+    cb, sb = C.c_int(0), C.c_int(0)
+    assert lib.nmpc_abi_sizes(C.byref(cb), C.byref(sb)) == 3
+    assert cb.value == C.sizeof(_lib.NmpcConfig) and sb.value == C.sizeof(_lib.NmpcStats)
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    from source_hash import source_hash
+    assert _lib.library_source_hash() == source_hash()
+    cfg = _lib.default_config()
+    assert cfg.qp_polish_passes == 8 and cfg.qp_polish_budget == 16 and cfg.qp_growth_max == 1e6 and cfg.qp_maxiter_status == 0
