@@ -115,6 +115,10 @@ typedef struct nmpc_config {
     double qp_acc_comp;        /* default 1e-8  ([UPSTREAM] HPIPM's default complementarity tolerance) */
     double qp_acc_stat;        /* default 1e-8 */
     double qp_tol_step;        /* convergence also needs the last step max |alpha d| / (ubu - lbu) <= this; default 1e-3, 0 = off */
+    int32_t qp_warm_start;     /* 1 (default): an active-set attempt that runs out of passes hands its last pass to the interior-point
+                                  iteration as the start point (inputs 1e-3 of the box inside the bounds, multipliers from the pass,
+                                  floored at mu = 1e-3) instead of the cold start; the next attempt then follows after one iteration   */
+    int32_t reserved_;
 } nmpc_config;
 
 typedef struct nmpc_stats {

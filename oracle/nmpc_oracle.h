@@ -73,6 +73,7 @@ typedef struct orc_config {
     int qp_maxiter_status;  /* [UPSTREAM] U10 switch: status returned when the QP hits qp_iter_max: 0 = tolerated (current
                                acados SQP_RTI), 2 = reported (some versions; the caller then discards the command,
                                controller.py:448-450) */
+    int qp_warm_start;      /* 1: an attempt that runs out of passes hands its last pass to the interior point as the start point */
 } orc_config;
 
 typedef struct orc_stats {

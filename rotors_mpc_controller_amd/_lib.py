@@ -42,6 +42,7 @@ class NmpcConfig(C.Structure):
         ("qp_polish", C.c_int32), ("qp_polish_passes", C.c_int32), ("qp_polish_budget", C.c_int32),
         ("qp_polish_mu", C.c_double), ("qp_polish_ckpt", C.c_int32), ("qp_maxiter_status", C.c_int32),
         ("qp_growth_max", C.c_double), ("qp_acc_comp", C.c_double), ("qp_acc_stat", C.c_double), ("qp_tol_step", C.c_double),
+        ("qp_warm_start", C.c_int32), ("reserved_", C.c_int32),
     ]
 
     def update(self, **over) -> "NmpcConfig":

@@ -231,6 +231,8 @@ void nmpc_default_config(nmpc_config *c)
     c->qp_acc_comp = 1e-8;
     c->qp_acc_stat = 1e-8;
     c->qp_tol_step = 1e-3;
+    c->qp_warm_start = 1;
+    c->reserved_ = 0;
 }
 
 static int ckpt_stages(const nmpc_config &g)

@@ -59,6 +59,7 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.acc_stat = (T)g.qp_acc_stat;
     c.tol_step = (T)g.qp_tol_step;
     c.maxiter_status = g.qp_maxiter_status;
+    c.warm_start = g.qp_warm_start;
 }
 
 

@@ -39,8 +39,9 @@ constexpr int NZ = 7;                 // stored columns of A: q (4) and omega (3
 constexpr int AD_SIZE = 79;           // 4*10 + 3*13
 constexpr int AB_ROWS = AD_SIZE + NX * NU;   // 131 rows per stage in the AB array
 constexpr int LM_ROWS = 10 + NU * NX + NU;   // L (10, diagonal stored inverted) + M (52) + m (4)
-constexpr int IV_ROWS = 24;           // u, lam_l, lam_u, u_aff, du  (4 each) | 4 spare slots: where lanes that carry no input of
-                                      // their own store, so that no store of a tile-form sweep is predicated
+constexpr int IV_ROWS = 36;           // u, lam_l, lam_u, u_aff, du  (4 each) | 4 spare slots: where lanes that carry no input of
+                                      // their own store, so that no store of a tile-form sweep is predicated | u, lam_l, lam_u of the warm start an exhausted
+                                      // active-set attempt leaves for the interior point (4 each)
 constexpr int QR_ROWS = NX + NU;      // q_k (13), r_k (4)
 
 NMPC_HD constexpr int ad_rows(int c) { return c < 4 ? 10 : 13; }
@@ -67,6 +68,7 @@ struct Consts {
     // FP64 tile kernels of nmpc_team_as.hpp; the oracle restates them in ocpqp_ipm / ocpqp_polish)
     T growth_max, acc_comp, acc_stat, tol_step;
     int maxiter_status;     // U10 switch: status of a QP that hits iter_max (0 tolerated, 2 reported)
+    int warm_start;         // an attempt that runs out of passes seeds the interior point (nmpc_config.qp_warm_start)
 };
 
 constexpr int TAB_ROWS = 192;       // doubles per stage of the team kernels' per-instance stage block tAB

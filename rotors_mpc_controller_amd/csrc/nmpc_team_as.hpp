@@ -336,6 +336,13 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     T sigmu = 0;
     using NoIpm = std::integral_constant<bool, false>;
     using Ipm = std::integral_constant<bool, true>;
+    using NoWarm = std::integral_constant<bool, false>;
+    using Warm = std::integral_constant<bool, true>;
+    // warm start of the interior point from an attempt that ran out of passes (nmpc_config.qp_warm_start; oracle ORC_WARM_*)
+    constexpr double WARM_DELTA = 1e-3, WARM_MU = 1e-3;
+    const T wd_a = T(WARM_DELTA) * (ub_a - lb_a);
+    bool anyp = false;       // the pass in flight had pinned inputs (lane-local; reduced per team)
+    bool warm_avail = false; // slots 24..35 of this team hold a warm start the interior point has not taken yet
     const T iw_a = T(1) / (ub_a - lb_a);          // step sizes are measured against the box width
 
     // ================= sweep A: backward factorisation in tile form.
@@ -621,9 +628,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     };
     // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
     // is one basic block; operands arrive two stages ahead in two alternating register sets
-    auto sweepB = [&](auto pins_tag, auto ipm_tag) {
+    auto sweepB = [&](auto pins_tag, auto ipm_tag, auto warm_tag) {
         constexpr bool PINS = decltype(pins_tag)::value;
         constexpr bool IPMV = decltype(ipm_tag)::value;     // predictor of an interior-point iteration: affine target, step length terms
+        constexpr bool WARM = decltype(warm_tag)::value;    // last pass of an attempt: also leaves the interior point's warm start (slots 24..35)
         T rmaxB = T(1), s2B = 0;                            // largest inverse step length (floor 1), complementarity of the affine step
         T AT2[4], AT3[4], BT[4];
         auto load_tiles_T = [&]() {
@@ -710,6 +718,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const T tolb = kkt_v * (T(1) + fabs(lo) + fabs(hi));
                 T npc = uj < lo - tolb ? T(-1) : (uj > hi + tolb ? T(1) : T(0));
                 T ue = uj;
+                T gpin = 0;                                                     // multiplier estimate of a pinned input (gradient of the QP's Lagrangian)
                 bool nanq = !(uj == uj);
                 if (PINS) {
                     const bool pin_here = pol2 && pc != T(0);
@@ -730,6 +739,18 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         const bool wrong = (pc < T(0) && g < -tolg) || (pc > T(0) && g > tolg);
                         npc = pin_here ? (wrong ? T(0) : pc) : npc;
                         nanq |= !(g == g);
+                        gpin = pin_here ? g : T(0);
+                    }
+                    if (WARM) {
+                        // warm start of the interior-point iteration in case this attempt ends here without an accepted pass
+                        // (oracle ocpqp_polish): the pass's inputs 1e-3 of the box width inside the bounds, multipliers = the
+                        // estimates of the pinned inputs floored at the central-path value of mu = 1e-3
+                        T v = fmin(fmax(ue, lo + wd_a), hi - wd_a);
+                        const T gl = pc < T(0) ? gpin : T(0), gh = pc > T(0) ? -gpin : T(0);
+                        ivk[tc == 0 ? 24 + ta : 20 + ta] = v;
+                        ivk[tc == 0 ? 28 + ta : 20 + ta] = fmax(gl, T(WARM_MU) * fast_rcp(v - lo));
+                        ivk[tc == 0 ? 32 + ta : 20 + ta] = fmax(gh, T(WARM_MU) * fast_rcp(hi - v));
+                        anyp |= pin_here;
                     }
                 }
                 if (TRAJ) ivk[cslot] = ue;                                     // every candidate input
@@ -1052,6 +1073,30 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         }
         msF = ms;
     };
+    // ================= warm start of the interior point: the last pass of an exhausted attempt (slots 24..35) becomes the iterate
+    // (slots 0..11); duality measure of that point.  Element-wise, stages spread over the lanes as in sweep F.
+    auto sweepW = [&](auto) {
+        T ms = 0;
+        constexpr int CHW = 5;
+        for (int k0 = 0; k0 < N; k0 += 4 * CHW) {
+            T w_u[CHW], w_l[CHW], w_h[CHW], w_ul[CHW];
+            NMPC_UNROLL for (int i = 0; i < CHW; i++) {
+                const int kq = k0 + 4 * i + tc;
+                const int k = kq < N ? kq : N - 1;
+                const T *ivn = tIV + k * IV_ROWS;
+                w_u[i] = ivn[24 + ta]; w_l[i] = ivn[28 + ta]; w_h[i] = ivn[32 + ta]; w_ul[i] = ulin(k, ta);
+            }
+            NMPC_UNROLL for (int i = 0; i < CHW; i++) {
+                const int kq = k0 + 4 * i + tc;
+                const bool live = kq < N;
+                T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
+                ivk[live ? ta : 20 + ta] = w_u[i]; ivk[live ? 4 + ta : 20 + ta] = w_l[i]; ivk[live ? 8 + ta : 20 + ta] = w_h[i];
+                const T lo = lb_a - w_ul[i], hi = ub_a - w_ul[i];
+                ms += live ? w_l[i] * (w_u[i] - lo) + w_h[i] * (hi - w_u[i]) : T(0);
+            }
+        }
+        msF = ms;
+    };
     // ================= state rollout from the inputs of the iterate (an instance that ends on the interior-point iterate): xhat_k
     // for the output sweep, NaN check of the step
     bool roll_bad = false;
@@ -1149,8 +1194,12 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         if (trip) { pol_fail = true; tripped = true; }  // not accurate enough to be accepted (see qp_growth_max): the attempt fails
         pol2 = mode == M_POL;
 
-        viol = false; heavy = false; kchgB = -1; xh = 0;
-        if (nopins_pass) sweepB(NoPins{}, NoIpm{}); else sweepB(WithPins{}, NoIpm{});
+        viol = false; heavy = false; kchgB = -1; xh = 0; anyp = false;
+        // the last pass of the attempt (wave-uniform: the live teams of a wave entered the attempt together)
+        const bool lastp = c.warm_start != 0 && __ballot(pol2 && pass_in_attempt == polish_passes - 1) != 0;
+        if (nopins_pass) sweepB(NoPins{}, NoIpm{}, NoWarm{});
+        else if (lastp) sweepB(WithPins{}, NoIpm{}, Warm{});
+        else sweepB(WithPins{}, NoIpm{}, NoWarm{});
         NMPC_STAMP(1)
         if (TRAJ) { if (rowl) tLM[66 + rr] = xh; }      // xhat_N parks in the unused xhat_0 slot (output sweep)
         __syncthreads();
@@ -1158,12 +1207,17 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         const bool t_viol = (__ballot(viol && tc == 0) & team_mask) != 0;
         const bool t_heavy = (__ballot((heavy && tc == 0) || !(xh == xh)) & team_mask) != 0;
         const int kc = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
+        const bool t_anyp = (__ballot(anyp && tc == 0) & team_mask) != 0;
         if (pol2) {
             npol++;
             pass_in_attempt++;
             const bool unclean = pol_fail || t_viol || t_heavy;
             if (!unclean) { mode = M_DONE; from_ua = true; }   // the pass satisfies the KKT conditions of the QP: accepted
-            else if (pol_fail || t_heavy || pass_in_attempt >= polish_passes) mode = M_GIVEUP;
+            else if (pol_fail || t_heavy || pass_in_attempt >= polish_passes) {
+                mode = M_GIVEUP;
+                // out of passes after a finished pass with pins: that pass seeds the interior-point iteration
+                warm_avail = lastp && !nopins_pass && !pol_fail && !t_heavy && t_anyp;
+            }
             else k_top = kc < ck_valid ? kc : N - 1;
         }
         pass++;
@@ -1184,25 +1238,43 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         const T nc = T(2 * NU) * T(N);
         T mu = c.mu0, rho = T(1), pol_mu = c.polish_mu, step_last = 0;
         bool have_point = false;
+        bool just_attempted = MODE == 2;   // an attempt has just failed: one interior-point iteration before the next one (oracle ocpqp_ipm)
         const bool attempt_first = MODE == 1 && c.polish && c.polish_budget > 0 && c.polish_passes > 0 && c.polish_mu >= c.mu0;
         bool first_free = attempt_first; // wave-uniform: the first active-set phase starts from "all inputs free"
         if (MODE == 2) {                 // the first attempt was made - and given up - by the active-set kernel
             const int np0 = w.npol[inst];
             npol = np0 < 0 ? -np0 : np0;
             pol_mu *= T(1e-2);
-            gbase = w.gbase[inst];
+            const T gb0 = w.gbase[inst];
+            gbase = fabs(gb0);
+            warm_avail = valid && gb0 < T(0);
             mode = valid ? M_IPM : M_DONE;
         } else {
             mode = valid ? (attempt_first ? M_WAIT : M_IPM) : M_DONE;
         }
         const int polish_budget = c.polish_budget, iter_max = c.iter_max > 0 ? c.iter_max : 1;
+        // the interior point takes over from an attempt that ran out of passes: that attempt's last pass becomes its iterate
+        auto install_warm = [&]() {
+            if (__ballot(warm_avail) != 0) {
+                tIV = warm_avail ? tIV_own : tIV_spare;
+                sweepW(Ipm{});
+                sh[r] = msF;
+                __syncthreads();
+                T ms = 0;
+                NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
+                if (warm_avail) { mu = ms / nc; rho = T(1); have_point = true; step_last = 0; }
+                warm_avail = false;
+                __syncthreads();
+            }
+        };
+        install_warm();
         for (;;) {
             // ---------------- interior-point phase
             for (;;) {
                 if (mode == M_IPM) {
                     if (!(mu == mu)) { status = 1; mode = M_DONE; }
                     else if (mu <= c.tol_comp && rho <= c.tol_stat && (it == 0 || !(c.tol_step > T(0)) || step_last <= c.tol_step)) mode = M_DONE;
-                    else if (c.polish && mu <= pol_mu && npol < polish_budget) mode = M_WAIT;
+                    else if (c.polish && mu <= pol_mu && npol < polish_budget && !just_attempted) mode = M_WAIT;
                     else if (it >= iter_max) { status = 2; mode = M_DONE; }
                 }
                 if (__ballot(mode == M_IPM) == 0) break;
@@ -1236,7 +1308,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const bool ipm2 = mode == M_IPM;
                 tLM = ipm2 ? tLM_own : tLM_spare; tIV = ipm2 ? tIV_own : tIV_spare;
                 viol = false; heavy = false; kchgB = -1; xh = 0;
-                sweepB(NoPins{}, Ipm{});
+                sweepB(NoPins{}, Ipm{}, NoWarm{});
                 NMPC_STAMP(1)
                 __syncthreads();
                 {
@@ -1272,6 +1344,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         mu = ms / nc;
                         step_last = alpha * dmx;
                     }
+                    just_attempted = false;
                 }
                 __syncthreads();   // sRed is reused by the next iteration
             }
@@ -1289,7 +1362,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     mode = M_IPM;
                     pol_mu *= T(1e-2);
                     if (tripped) npol = polish_budget;
+                    just_attempted = true;
                 }
+                install_warm();
             }
             if (__ballot(mode != M_DONE) == 0) break;
         }
@@ -1321,7 +1396,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             // the work-list launch resumes the pass budget from here (all of it spent when the growth certificate ended the
             // attempt: the same pins would fail the same way) and compares against the same first factorisation
             w.npol[inst] = -(tripped ? c.polish_budget : npol);
-            w.gbase[inst] = gbase;
+            w.gbase[inst] = warm_avail ? -gbase : gbase;     // < 0: the attempt ran out of passes, its last pass seeds the interior point
             const int slot = atomicAdd(wl.count, 1);
             wl.list[slot] = inst;
         }

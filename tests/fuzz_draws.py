@@ -61,7 +61,7 @@ def oracle_config(over, **extra):
                          rotor_y=list(cfg.rotor_y), rotor_z=list(cfg.rotor_z), sim_num_steps=cfg.sim_num_steps,
                          qp_iter_max=cfg.qp_iter_max, qp_gamma=0.0, qp_polish=cfg.qp_polish,
                          qp_growth_max=cfg.qp_growth_max, qp_acc_comp=cfg.qp_acc_comp, qp_acc_stat=cfg.qp_acc_stat,
-                         qp_tol_step=cfg.qp_tol_step, qp_maxiter_status=cfg.qp_maxiter_status)
+                         qp_tol_step=cfg.qp_tol_step, qp_maxiter_status=cfg.qp_maxiter_status, qp_warm_start=cfg.qp_warm_start)
     for k, v in extra.items():
         setattr(c, k, v)
     return c

@@ -15,7 +15,7 @@ class OracleOcpSolver:
                                   rotor_z=list(cfg.rotor_z), sim_num_steps=cfg.sim_num_steps,
                                   qp_iter_max=cfg.qp_iter_max, qp_gamma=0.0, qp_growth_max=cfg.qp_growth_max,
                                   qp_acc_comp=cfg.qp_acc_comp, qp_acc_stat=cfg.qp_acc_stat, qp_tol_step=cfg.qp_tol_step,
-                                  qp_maxiter_status=cfg.qp_maxiter_status)
+                                  qp_maxiter_status=cfg.qp_maxiter_status, qp_warm_start=cfg.qp_warm_start)
         self.x = np.zeros((self.N + 1, 13)); self.u = np.zeros((self.N, 4))
         self.yref = np.zeros((self.N, 17)); self.yref_e = np.zeros(13); self.x0 = np.zeros(13)
 

@@ -432,7 +432,9 @@ def test_tile_form_row_form_and_unfused_launch_agree(share, monkeypatch):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)
-        s = make_solver(flags=(1 if share else 0) | _lib.FLAG_TEAM_MAPPING)      # the knobs are read at create
+        # (qp_warm_start = 0: the round-1 kernels - row form, two-kernel launch - carry neither the warm start of the interior
+        # point from an exhausted attempt nor the growth certificate; with both off the three are the same algorithm)
+        s = make_solver(flags=(1 if share else 0) | _lib.FLAG_TEAM_MAPPING, qp_warm_start=0, qp_growth_max=0.0, qp_tol_step=0.0)      # the knobs are read at create
         yref, ye = hover(s.config)
         o = s.solve_batch(x0, yref, ye, want_traj=True)
         st = s.stats()
