@@ -551,7 +551,8 @@ def main() -> None:
         # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
         traffic, traffic_note = None, None
         split = st.get("ms_tail", 0.0) > 0.0          # default FP64 path: active-set kernel + work-list launch of the general kernel
-        kname = ("k_team_as" if split else "k_team_ipm") if args.mapping == "team" else "k_ipm"
+        new_qp = args.dtype in ("f64", "f32io") and os.environ.get("NMPC_TEAM_QP", "1") != "0" and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
+        kname = ("k_team_as" if split else ("k_team_qp" if new_qp else "k_team_ipm")) if args.mapping == "team" else "k_ipm"
         pmc_file = ROOT / "profiles" / f"latest_{args.mapping}_b{B}_{args.dtype}_pmc_summary.json"
         if pmc_file.exists() and not args.no_share and not bcast and not args.traj_out and N == 20:
             pmc_all = json.loads(pmc_file.read_text())
@@ -565,10 +566,10 @@ def main() -> None:
                 traffic_note = f"stale profile: {pmc_file.name} was captured on kernel sources {pmc_all.get('source_hash')}, this build is {source_hash()}"
             elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-                tail = pmc_all.get("k_team_ipm_list", {})
+                tail = pmc_all.get("k_team_qp_list", pmc_all.get("k_team_ipm_list", {}))
                 if split and "FETCH_SIZE" in tail and "WRITE_SIZE" in tail:      # both launches of a step
                     traffic += (2.0 * tail["FETCH_SIZE"]["mean"] + tail["WRITE_SIZE"]["mean"]) * 1024.0
-        kernel_name = ("k_team_as + k_team_ipm_list" if split else "k_team_ipm") if args.mapping == "team" else "k_ipm"
+        kernel_name = ("k_team_as + k_team_qp_list" if split else kname) if args.mapping == "team" else "k_ipm"
         hbm = dict(achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS,
                    algorithmic_bytes_per_solve=alg_b,
                    measured_traffic_gbs=(traffic / kern_s / 1e9 if traffic is not None else None))
@@ -586,7 +587,7 @@ def main() -> None:
         mfma_path = args.mapping == "team" and args.dtype in ("f64", "f32io") and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
         common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else traffic_note),
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + st.get("ms_tail", 0.0), prepare_ms=st["ms_prepare"],
-                      launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_ipm_list_ms_isolated=st["ms_tail"],
+                      launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=st["ms_tail"],
                                      instances_in_second_launch=st["n_tail"],
                                      note="kernel_ms = device time of one step = both launches (HIP events around the timed region)")
                                 if split else None), hbm=hbm, alu=flop)

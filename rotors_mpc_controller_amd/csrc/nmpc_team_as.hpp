@@ -781,9 +781,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     const T *iv1 = tIV + (1 < N ? 1 : 0) * IV_ROWS;
                     m_u = iv1[ta]; m_ll = iv1[4 + ta]; m_lu = iv1[8 + ta];
                 }
-                fetch_ops_lds(0, ol);
-                for (int k = 0; k < kl; k++) {
-                    ol.ul = n_ul; ol.pc = n_pc; ol.u = n_u; ol.ll = n_ll; ol.lu = n_lu;
+                // the factors of stage k + 1 leave LDS before stage k computes (two operand sets, alternating): a stage is a short
+                // chain of dependent MFMAs and would otherwise open with an exposed LDS round trip
+                Ops ol2;
+                auto scalars = [&](Ops &o, int k) {
+                    o.ul = n_ul; o.pc = n_pc; o.u = n_u; o.ll = n_ll; o.lu = n_lu;
                     const int kn = k + 1 < N ? k + 1 : k;
                     n_ul = ulin(kn, ta);
                     if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
@@ -792,8 +794,17 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                         const T *ivn = tIV + (k + 2 < N ? k + 2 : N - 1) * IV_ROWS;
                         m_u = ivn[ta]; m_ll = ivn[4 + ta]; m_lu = ivn[8 + ta];
                     }
+                };
+                fetch_ops_lds(0, ol);
+                for (int k = 0; k < kl; k += 2) {
+                    if (k + 1 < kl) fetch_ops_lds(k + 1, ol2);
+                    scalars(ol, k);
                     stageB(k, ol);
-                    if (k + 1 < kl) fetch_ops_lds(k + 1, ol);
+                    if (k + 1 < kl) {
+                        if (k + 2 < kl) fetch_ops_lds(k + 2, ol);
+                        scalars(ol2, k + 1);
+                        stageB(k + 1, ol2);
+                    }
                 }
             }
         }
@@ -927,12 +938,22 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 OpsD ol, on, on2;                          // scalars two stages ahead, as in sweep E
                 fetch_sc(kl - 1, on);
                 fetch_sc(kl - 2, on2);
-                for (int k = kl - 1; k >= 0; k--) {
-                    fetch_d_lds(k, ol);
-                    ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
+                OpsD ol2;
+                auto scalars = [&](OpsD &o, int k) {
+                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.ua = on.ua; o.ul = on.ul;
                     on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
                     fetch_sc(k - 2, on2);
+                };
+                fetch_d_lds(kl - 1, ol);
+                for (int k = kl - 1; k >= 0; k -= 2) {        // factors one stage ahead, two operand sets (as sweep B)
+                    if (k >= 1) fetch_d_lds(k - 1, ol2);
+                    scalars(ol, k);
                     stageD(k, ol, Tr{});
+                    if (k >= 1) {
+                        if (k >= 2) fetch_d_lds(k - 2, ol);
+                        scalars(ol2, k - 1);
+                        stageD(k - 1, ol2, Tr{});
+                    }
                 }
             }
         }
@@ -1017,13 +1038,22 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 OpsE ol, on, on2;
                 fetch_sc(0, on);
                 fetch_sc(1 < N ? 1 : 0, on2);
-                fetch_e_lds(0, ol);
-                for (int k = 0; k < kl; k++) {
-                    ol.u = on.u; ol.ll = on.ll; ol.lu = on.lu; ol.ua = on.ua; ol.ul = on.ul;
+                OpsE ol2;
+                auto scalars = [&](OpsE &o, int k) {
+                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.ua = on.ua; o.ul = on.ul;
                     on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
                     fetch_sc(k + 2 < N ? k + 2 : N - 1, on2);
+                };
+                fetch_e_lds(0, ol);
+                for (int k = 0; k < kl; k += 2) {            // factors of stage k + 1 out of LDS before stage k computes (as sweep B)
+                    if (k + 1 < kl) fetch_e_lds(k + 1, ol2);
+                    scalars(ol, k);
                     stageE(k, ol);
-                    if (k + 1 < kl) fetch_e_lds(k + 1, ol);
+                    if (k + 1 < kl) {
+                        if (k + 2 < kl) fetch_e_lds(k + 2, ol);
+                        scalars(ol2, k + 1);
+                        stageE(k + 1, ol2);
+                    }
                 }
             }
         }

@@ -6,7 +6,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/rocprof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 6 --warmup 2 --no-cpu-baseline ${BENCH_ARGS}"
+ARGS="--steps 6 --warmup 2 --no-cpu-baseline --no-secondary ${BENCH_ARGS}"
 run() { rocprofv3 --pmc $2 --output-format csv -d $OUT/$1 -- python3 $REPO/bench.py $ARGS > $OUT/$1.log 2>&1 || echo "pass $1 failed"; }
 run pmc_sq  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"
 run pmc_sq2 "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU"

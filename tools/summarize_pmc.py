@@ -17,7 +17,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"
     meta = {}
     for r in csv.DictReader(open(files[0])):
         kn = r["Kernel_Name"]
-        k = next((t for t in ("k_team_as", "k_team_ipm_list", "k_team_ipm", "k_team_prepare", "k_ipm", "k_prepare") if t + "<" in kn), None)
+        k = next((t for t in ("k_team_as", "k_team_qp_list", "k_team_qp", "k_team_ipm_list", "k_team_ipm", "k_team_prepare", "k_ipm", "k_prepare") if t + "<" in kn), None)
         if k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = dict(vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
@@ -27,13 +27,11 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"
         out.setdefault(k, {})[c] = dict(dispatches=len(v), mean=sum(v) / len(v))
     for k, m in meta.items():
         out.setdefault(k, {})["launch"] = m
-import hashlib
 import pathlib
-h = hashlib.sha1()
-for f in sorted((pathlib.Path(__file__).resolve().parent.parent / "rotors_mpc_controller_amd" / "csrc").glob("*.h*")):
-    h.update(f.name.encode())
-    h.update(f.read_bytes())
-out["source_hash"] = h.hexdigest()[:12]      # bench.py quotes this traffic only on a build with the same hash
+import sys as _sys
+_sys.path.insert(0, str(pathlib.Path(__file__).resolve().parent))
+from source_hash import source_hash as _sh
+out["source_hash"] = _sh()      # bench.py quotes this traffic only on a build with the same hash
 json.dump(out, open(out_path, "w"), indent=1)
 for k, v in out.items():
     if not isinstance(v, dict):
