@@ -127,7 +127,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     (void)lane;
     const int N = c.N;
     T *S = smem + team * LDS_T;
-    T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sD = S + A_D, *sh = S + A_H, *sXh = S + A_XH;
+    T *sAd = S + A_AD, *sB = S + A_B, *sbv = S + A_BV, *sHg = S + A_HG, *sh = S + A_H, *sXh = S + A_XH;
     T *sRed = S + A_RED, *sEv = S + A_EV, *sLM = S + lm_off;
     const bool warm = !SHARED && in.x_init != nullptr && in.u_init != nullptr;
     const TI *x0p = in.x0 + (size_t)inst * NX;
@@ -155,8 +155,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     // constant block cost a 13-way select chain per entry and 190 scalar registers - 584 of the 1413 instructions
     // in front of the first MFMA were scalar-register spill traffic)
     const T Wq_r = c.Wq[rr], WqN_r = c.WqN[rr];
-    const T Wr_j = c.Wr[j], Wr_a = c.Wr[ta];
-    const T lbj = c.lbu[j], ubj = c.ubu[j], Rdj = c.Rd[j];
+    const T Wr_a = c.Wr[ta];
+    const T lbj = c.lbu[j], ubj = c.ubu[j];
     const T lb_a = c.lbu[ta], ub_a = c.ubu[ta], Rd_a = c.Rd[ta];
     T Qdg[4];                              // diagonal of the stage Hessian in tile layout
     NMPC_UNROLL for (int t = 0; t < 4; t++) {
@@ -388,11 +388,15 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             }
         }
         // scalars of a stage are fetched one stage ahead (global loads stay in flight over the stage):
-        // reference row rr, reference / linearisation input of component j (pins) or a (no pins), pin code
-        const int cu = PINS ? j : ta;
+        // reference row rr, reference / linearisation input of component a; pins variant: the pin codes of inputs a AND c (and the
+        // linearisation input of component c) - lane (a,c) then forms the masks, the pinned values and the modified gradient of
+        // BOTH its inputs in registers (in round 2 lanes 0..3 computed them and the team exchanged them through LDS: four
+        // predicated stores, five reads and a hand-off at the head of every stage)
+        const int cu = ta;
         T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + cu];
         T n_xl = xlin(ks), n_ul = ulin(ks, cu);
         T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
+        T n_pca = PINS ? tIV[ks * IV_ROWS + 16 + ta] : T(0), n_ulc = PINS ? ulin(ks, j) : T(0);
         T n_u = 0, n_ll = 0, n_lu = 0;                       // the iterate of input a (interior-point variant)
         if (IPMV) { n_u = tIV[ks * IV_ROWS + ta]; n_ll = tIV[ks * IV_ROWS + 4 + ta]; n_lu = tIV[ks * IV_ROWS + 8 + ta]; }
         auto stage = [&](int k, auto last_tag, auto lds_tag) {
@@ -403,18 +407,18 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 if (!LAST) fetch_stage(k - 1, r);
             }
             T *lmk = tLM + k * TLM_ROWS;
-            const T ul = n_ul, pc = n_pc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
+            const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
             // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
             // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
             // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
             // (found by the permutation test at N = 600)
-            T rk = (PINS ? Wr_j : Wr_a) * (ul - n_yu);
+            T rk = Wr_a * (ul - n_yu);
             const T q_r = Wq_r * (n_xl - n_yx);
             asm volatile("" : "+v"(rk));             // (q_r passes through LDS, which rounds it in both variants)
             if (!LAST) {
                 n_yx = (T)yr[(size_t)(k - 1) * NY + rr]; n_yu = (T)yr[(size_t)(k - 1) * NY + NX + cu];
                 n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
-                if (PINS) n_pc = tIV[(k - 1) * IV_ROWS + 16 + j];
+                if (PINS) { n_pc = tIV[(k - 1) * IV_ROWS + 16 + j]; n_pca = tIV[(k - 1) * IV_ROWS + 16 + ta]; n_ulc = ulin(k - 1, j); }
                 if (IPMV) { const T *ivn = tIV + (k - 1) * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
             }
             T mask_a = T(1), mask_c = T(1), D_a = Rd_a, rhat_a = rk;
@@ -432,20 +436,15 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             if (PINS) {
                 // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps
                 // R_jj so that u_j = bound
-                const T lo = lbj - ul, hi = ubj - ul;
-                const bool pinned = pol && pc != T(0);
-                const T vpin = pc < T(0) ? lo : hi;
-                if (cmpl) {
-                    sD[j] = Rdj;
-                    sD[4 + j] = pinned ? -Rdj * vpin : rk;
-                    sD[8 + j] = pinned ? T(0) : T(1);
-                    sD[12 + j] = pinned ? vpin : T(0);
-                }
-                NMPC_WSYNC();
-                mask_a = sD[8 + ta]; mask_c = sD[8 + tc]; D_a = sD[ta]; rhat_a = sD[4 + ta];
+                const bool pinned_a = pol && pca != T(0), pinned = pol && pc != T(0);      // input a | input c of this lane
+                const T vpin_a = pca < T(0) ? lb_a - ul : ub_a - ul;
+                const T vpin_c = pc < T(0) ? lbj - ulc : ubj - ulc;
+                mask_a = pinned_a ? T(0) : T(1); mask_c = pinned ? T(0) : T(1);
+                D_a = Rd_a;
+                rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
                 any_pins = __ballot(pinned) != 0;
                 if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
-                    const T vp = sD[12 + tc];
+                    const T vp = pinned ? vpin_c : T(0);
                     NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                         const T sm = quad_sum(Bt[kt] * vp);
                         if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
