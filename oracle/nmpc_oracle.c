@@ -652,13 +652,18 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
                 const double lo = p->lo[k][i], hi = p->hi[k][i], w = hi - lo;
-                double v = uh[k][i];
-                if (v < lo + ORC_WARM_DELTA * w) v = lo + ORC_WARM_DELTA * w;
-                if (v > hi - ORC_WARM_DELTA * w) v = hi - ORC_WARM_DELTA * w;
+                /* a pinned input keeps its multiplier estimate g and takes the slack mu / g that puts the pair ON the central
+                 * path of mu (at most delta * w: a small g is floored instead); every other pair sits on it by construction */
                 const double gl = pin[k][i] < 0 ? gsave[k][i] : 0.0, gh = pin[k][i] > 0 ? -gsave[k][i] : 0.0;
+                double tl = ORC_WARM_DELTA * w, th = ORC_WARM_DELTA * w;
+                if (gl * tl > ORC_WARM_MU) tl = ORC_WARM_MU / gl;
+                if (gh * th > ORC_WARM_MU) th = ORC_WARM_MU / gh;
+                double v = uh[k][i];
+                if (v < lo + tl) v = lo + tl;
+                if (v > hi - th) v = hi - th;
                 u[k][i] = v;
-                ll[k][i] = fmax(gl, ORC_WARM_MU / (v - lo));
-                lu[k][i] = fmax(gh, ORC_WARM_MU / (hi - v));
+                ll[k][i] = ORC_WARM_MU / (v - lo);
+                lu[k][i] = ORC_WARM_MU / (hi - v);
             }
     }
     if (ok) {
@@ -686,6 +691,24 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
  * Feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
  * states are implied by the (affine) dynamics, so the only residuals are stationarity
  * (scales by 1-alpha per step; tracked as rho) and complementarity (mu).                */
+/* standard (cold) start point of the interior-point iteration: inputs pushed inside the box, multipliers on the central path of mu0 */
+static void ipm_cold_point(const orc_config *c, const ocpqp *p, double **u, double **ll, double **lu)
+{
+    for (int k = 0; k < p->N; k++)
+        for (int i = 0; i < p->nu[k]; i++) {
+            const double lo = p->lo[k][i], hi = p->hi[k][i];
+            double thr = c->qp_thr0;
+            if (c->qp_thr0_rel * (hi - lo) > thr) thr = c->qp_thr0_rel * (hi - lo);
+            if (hi - lo < 2.0 * thr) thr = 0.5 * (hi - lo);
+            double v = 0.0;
+            if (v - lo < thr) v = lo + thr;
+            if (hi - v < thr) v = hi - thr;
+            u[k][i] = v;
+            ll[k][i] = c->qp_mu0 / (v - lo);
+            lu[k][i] = c->qp_mu0 / (hi - v);
+        }
+}
+
 static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                      double **u /*out*/, double *x /*out (N+1)*NX*/, orc_stats *st)
 {
@@ -707,22 +730,12 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         f.L[k] = dalloc((size_t)m * m); f.M[k] = dalloc((size_t)m * NX); f.m[k] = dalloc(m);
         ll[k] = dalloc(m); lu[k] = dalloc(m); sig[k] = dalloc(m); rh[k] = dalloc(m);
         ua[k] = dalloc(m); du[k] = dalloc(m); dla[k] = dalloc(m); dua[k] = dalloc(m);
-        for (int i = 0; i < m; i++) {
-            const double lo = p->lo[k][i], hi = p->hi[k][i];
-            double thr = c->qp_thr0;
-            if (c->qp_thr0_rel * (hi - lo) > thr) thr = c->qp_thr0_rel * (hi - lo);
-            if (hi - lo < 2.0 * thr) thr = 0.5 * (hi - lo);
-            double v = 0.0;
-            if (v - lo < thr) v = lo + thr;
-            if (hi - v < thr) v = hi - thr;
-            u[k][i] = v;
-            ll[k][i] = c->qp_mu0 / (v - lo);
-            lu[k][i] = c->qp_mu0 / (hi - v);
-        }
     }
+    ipm_cold_point(c, p, u, ll, lu);
     double rho = 1.0, mu = 0.0, pol_mu = c->qp_polish_mu;
     double gbase = 0.0, growth = 0.0, step_last = 0.0;
     int polished = 0, npolish = 0, untrusted = 0;
+    int warm_derived = 0;   /* the iterate descends from a warm start (an exhausted attempt's last pass), not from the cold point */
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
     for (;;) {
         mu = 0.0;
@@ -734,8 +747,10 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat && (it == 0 || !(c->qp_tol_step > 0.0) || step_last <= c->qp_tol_step)) break;
         if (c->qp_polish && mu <= pol_mu && npolish < c->qp_polish_budget) {
             int trip = 0, warm = 0;
+            /* the warm start is for the iteration BETWEEN two attempts: an attempt that uses up the budget leaves the iterate alone */
+            const int last_attempt = npolish + c->qp_polish_passes >= c->qp_polish_budget;
             if (ocpqp_polish(p, dx0, &f, u, ll, lu, x, c->qp_polish_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip,
-                             c->qp_warm_start ? &warm : NULL)) {
+                             (c->qp_warm_start && !last_attempt) ? &warm : NULL)) {
                 polished = 1; mu = 0.0; rho = 0.0; break;
             }
             if (trip) { untrusted = 1; npolish = c->qp_polish_budget; }     /* the same pins would fail the same way: no further attempt */
@@ -747,8 +762,17 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                         mu += ll[k][i] * (u[k][i] - p->lo[k][i]) + lu[k][i] * (p->hi[k][i] - u[k][i]);
                 mu /= nc;
                 rho = 1.0;
+                warm_derived = 1;
                 /* (pol_mu is not touched: the warm point's mu ~ 1e-3 is already below the threshold of the next attempt, which
                  * therefore follows after ONE interior-point iteration - the iteration that re-derives the active-set guess) */
+            } else if (warm_derived && npolish >= c->qp_polish_budget) {
+                /* no attempt is left and the iterate in hand descends from a warm start - off the central path, a poor place to
+                 * converge from (42 iterations and 1e-6 of accuracy on fuzz draw 353, against 15 and 2e-8): the interior point
+                 * finishes the QP from its standard cold point                                                                */
+                ipm_cold_point(c, p, u, ll, lu);
+                mu = c->qp_mu0;
+                rho = 1.0;
+                warm_derived = 0;
             }
         }
         if (it >= itmax) { status = 2; break; }

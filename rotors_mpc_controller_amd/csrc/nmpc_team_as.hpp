@@ -343,6 +343,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     const T wd_a = T(WARM_DELTA) * (ub_a - lb_a);
     bool anyp = false;       // the pass in flight had pinned inputs (lane-local; reduced per team)
     bool warm_avail = false; // slots 24..35 of this team hold a warm start the interior point has not taken yet
+    bool warm_derived = false; // the interior point's iterate descends from a warm start, not from the cold point
     const T iw_a = T(1) / (ub_a - lb_a);          // step sizes are measured against the box width
 
     // ================= sweep A: backward factorisation in tile form.
@@ -742,13 +743,17 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     }
                     if (WARM) {
                         // warm start of the interior-point iteration in case this attempt ends here without an accepted pass
-                        // (oracle ocpqp_polish): the pass's inputs 1e-3 of the box width inside the bounds, multipliers = the
-                        // estimates of the pinned inputs floored at the central-path value of mu = 1e-3
-                        T v = fmin(fmax(ue, lo + wd_a), hi - wd_a);
+                        // (oracle ocpqp_polish): a pinned input keeps its multiplier estimate g and takes the slack mu / g that
+                        // puts the pair ON the central path of mu = 1e-3 (at most 1e-3 of the box width: a small g is floored
+                        // instead); every other pair sits on that path by construction
                         const T gl = pc < T(0) ? gpin : T(0), gh = pc > T(0) ? -gpin : T(0);
+                        T tl = wd_a, th = wd_a;
+                        tl = gl * tl > T(WARM_MU) ? T(WARM_MU) * fast_rcp(gl > T(0) ? gl : T(1)) : tl;
+                        th = gh * th > T(WARM_MU) ? T(WARM_MU) * fast_rcp(gh > T(0) ? gh : T(1)) : th;
+                        const T v = fmin(fmax(ue, lo + tl), hi - th);
                         ivk[tc == 0 ? 24 + ta : 20 + ta] = v;
-                        ivk[tc == 0 ? 28 + ta : 20 + ta] = fmax(gl, T(WARM_MU) * fast_rcp(v - lo));
-                        ivk[tc == 0 ? 32 + ta : 20 + ta] = fmax(gh, T(WARM_MU) * fast_rcp(hi - v));
+                        ivk[tc == 0 ? 28 + ta : 20 + ta] = T(WARM_MU) * fast_rcp(v - lo);
+                        ivk[tc == 0 ? 32 + ta : 20 + ta] = T(WARM_MU) * fast_rcp(hi - v);
                         anyp |= pin_here;
                     }
                 }
@@ -1225,7 +1230,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
 
         viol = false; heavy = false; kchgB = -1; xh = 0; anyp = false;
         // the last pass of the attempt (wave-uniform: the live teams of a wave entered the attempt together)
-        const bool lastp = c.warm_start != 0 && __ballot(pol2 && pass_in_attempt == polish_passes - 1) != 0;
+        // ... and a later attempt is still allowed: the warm start is for the interior-point iteration BETWEEN two attempts
+        const bool warm_ok = pass_in_attempt == polish_passes - 1 && npol - pass_in_attempt + polish_passes < c.polish_budget;
+        const bool lastp = c.warm_start != 0 && __ballot(pol2 && warm_ok) != 0;
         if (nopins_pass) sweepB(NoPins{}, NoIpm{}, NoWarm{});
         else if (lastp) sweepB(WithPins{}, NoIpm{}, Warm{});
         else sweepB(WithPins{}, NoIpm{}, NoWarm{});
@@ -1237,6 +1244,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         const bool t_heavy = (__ballot((heavy && tc == 0) || !(xh == xh)) & team_mask) != 0;
         const int kc = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
         const bool t_anyp = (__ballot(anyp && tc == 0) & team_mask) != 0;
+        const bool warm_ok_prev = warm_ok;
         if (pol2) {
             npol++;
             pass_in_attempt++;
@@ -1245,7 +1253,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             else if (pol_fail || t_heavy || pass_in_attempt >= polish_passes) {
                 mode = M_GIVEUP;
                 // out of passes after a finished pass with pins: that pass seeds the interior-point iteration
-                warm_avail = lastp && !nopins_pass && !pol_fail && !t_heavy && t_anyp;
+                warm_avail = lastp && warm_ok_prev && !nopins_pass && !pol_fail && !t_heavy && t_anyp;
             }
             else k_top = kc < ck_valid ? kc : N - 1;
         }
@@ -1291,7 +1299,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 __syncthreads();
                 T ms = 0;
                 NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
-                if (warm_avail) { mu = ms / nc; rho = T(1); have_point = true; step_last = 0; }
+                if (warm_avail) { mu = ms / nc; rho = T(1); have_point = true; step_last = 0; warm_derived = true; }
                 warm_avail = false;
                 __syncthreads();
             }
@@ -1392,6 +1400,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     pol_mu *= T(1e-2);
                     if (tripped) npol = polish_budget;
                     just_attempted = true;
+                    if (!warm_avail && warm_derived && npol >= polish_budget) {
+                        // no attempt is left and the iterate in hand descends from a warm start - off the central path, a poor
+                        // place to converge from: the interior point finishes the QP from its standard cold point (oracle ocpqp_ipm)
+                        have_point = false; mu = c.mu0; rho = T(1); warm_derived = false;
+                    }
                 }
                 install_warm();
             }

@@ -63,6 +63,14 @@ def test_oracle_matches_acados_and_names_the_convention():
     print(f"acados {g['acados_version']} ({g['nlp_solver_type']}): rel. error per (lm_scaled_by_dt, cost_scaled_by_dt): {table}")
     assert table[best] <= 1e-6, f"no switch setting reproduces acados: {table}"
     assert best == (1, 1), f"the shipped defaults (1, 1) are not this acados version's convention; {best} is: {table}"
+    # U10: the status this acados returns when the QP hits its iteration cap names the qp_maxiter_status setting (0 tolerated, 2 reported)
+    if "status_itercap" in g.files:
+        seen = sorted(set(int(v) for v in g["status_itercap"]))
+        assert set(seen) <= {0, 2}, f"unexpected status for a capped QP: {seen}"
+        convention = 2 if 2 in seen else 0
+        print(f"acados {g['acados_version']}: a QP stopped by qp_solver_iter_max returns status {seen} -> qp_maxiter_status = {convention}")
+        assert convention == O.default_config().qp_maxiter_status, \
+            f"the shipped default qp_maxiter_status = {O.default_config().qp_maxiter_status} is not this acados version's behaviour ({convention})"
 
 
 @needs_golden

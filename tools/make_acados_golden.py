@@ -75,7 +75,8 @@ def build_model(p):
     return m
 
 
-def build_solver(p, workdir: Path):
+def build_solver(p, workdir: Path, qp_iter_max=None):
+    """qp_iter_max: override of solver_iter_max (the U10 probe: what status does this acados return when the QP hits its cap?)"""
     from acados_template import AcadosOcp, AcadosOcpSolver
     N = int(p.horizon_steps)
     ocp = AcadosOcp()
@@ -87,7 +88,7 @@ def build_solver(p, workdir: Path):
     so.hessian_approx = "GAUSS_NEWTON"                       # :182
     so.integrator_type = "ERK"                               # :183
     so.qp_solver_cond_N = min(N, 5)                          # :184
-    so.qp_solver_iter_max = int(p.solver_iter_max)           # :185
+    so.qp_solver_iter_max = int(p.solver_iter_max if qp_iter_max is None else qp_iter_max)           # :185
     so.collocation_type = "GAUSS_RADAU_IIA"                  # :186 (no effect on ERK)
     so.sim_method_num_stages = 2                             # :187
     so.sim_method_num_steps = 2                              # :188
@@ -171,12 +172,22 @@ def main():
             except Exception:
                 it.append(-1)
         nlp_type = str(getattr(ocp.solver_options, "nlp_solver_type", "?"))
+    # U10 probe (nmpc_config.qp_maxiter_status): the same OCP with the QP capped at ONE iteration, on the first eight
+    # fixture states - the status acados returns for "QP hit its iteration cap" (0 = tolerated, 2 = reported) and the command it
+    # leaves are version-dependent
+    st_cap, u0_cap = [], []
+    with tempfile.TemporaryDirectory() as td:
+        _, solver1 = build_solver(p, Path(td), qp_iter_max=1)
+        for x in x0[:8]:
+            solver1.reset() if hasattr(solver1, "reset") else None
+            a, s, _, _, _ = cold_start_rti(solver1, N, x, yref, yref_e)
+            st_cap.append(s); u0_cap.append(a)
     np.savez_compressed(
         args.out, x0=x0, yref=yref, yref_e=yref_e, u0=np.array(u0), status=np.array(st, dtype=np.int32),
         x=np.array(xs), u=np.array(us), qp_iter=np.array(it, dtype=np.int32), solve_seconds=np.array(ts),
         acados_version=np.array(str(getattr(acados_template, "__version__", "unknown"))),
         casadi_version=np.array(str(getattr(casadi, "__version__", "unknown"))), nlp_solver_type=np.array(nlp_type),
-        n_fixture=np.array(fx["x0"].shape[0]))
+        n_fixture=np.array(fx["x0"].shape[0]), status_itercap=np.array(st_cap, dtype=np.int32), u0_itercap=np.array(u0_cap))
     print(f"wrote {args.out}: {len(x0)} instances, status histogram {np.bincount(np.array(st), minlength=5)}, "
           f"nlp_solver_type {nlp_type}, median solve() {1e6 * float(np.median(ts)):.0f} us")
 
