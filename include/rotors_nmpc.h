@@ -259,6 +259,27 @@ int nmpc_adjoint_sensitivities_device(nmpc_solver *s, int B, const void *x, cons
 int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void *u_traj, const void *yref, const void *yref_e,
                            int yref_bcast, void *res, void *hip_stream);
 
+/* Parallel-in-time Riccati factorisation of ONE active-set pass (controller.py:184 asks HPIPM for partial condensing
+ * into qp_solver_cond_N = min(N, 5) blocks; cfg/rotors_mpc.cfg:9 lets the horizon reach 600).  The horizon is cut into `blocks`
+ * blocks that are swept by their own teams AT THE SAME TIME, with `blocks - 1` sequential boundary updates in between
+ * (csrc/nmpc_block.hpp has the algebra) - the blocks of the reference's condensing, used as parallelism instead of as 480-input
+ * dense stages.  Building block and diagnostic: it is not on the path of nmpc_solve_batch* yet.
+ *   The LQ problem factorised is the one the LAST solve of this handle ended on - its per-stage linearisation (so that solve must
+ *   have been warm-started, or NMPC_FLAG_SHARE_COLD_START off) and the pin set its last forward sweep left; x0 .. u_init are the
+ *   device arrays that solve was given.  FP64 arithmetic in the team mapping only.
+ *   factors_out  [B][N][80]  doubles, or NULL: per stage Mbar' as 4 tiles x 16 lanes | the L^-1 tile (the layout of the solver's own sweeps)
+ *   boundary_out [B][J+1][256] doubles, or NULL: value function Pbar (16 tiles x 16 lanes) at the start of block j
+ *   check_out    [B][J+1][256] doubles, or NULL: the same as recomputed by block j's own final sweep (blocks 0 .. J-2)
+ *   ms_out       float[3], or NULL: device time of the three launches (synchronises)
+ * blocks = 1 is the sequential sweep in the same code.  Returns J, the number of blocks that hold stages (<= blocks), or < 0. */
+int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, const void *yref, const void *yref_e, int yref_bcast,
+                             const void *x_init, const void *u_init, double *factors_out, double *boundary_out, double *check_out,
+                             float *ms_out, void *hip_stream);
+
+/* diagnostic: the factors the last solve's own sweeps left in the workspace, to the HOST [B][N][80] (same layout as factors_out;
+ * complete only for a solve that ran without the LDS stage cache, NMPC_TEAM_LSTG=0) */
+int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out);
+
 /* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */
 const char *nmpc_version(void);
 

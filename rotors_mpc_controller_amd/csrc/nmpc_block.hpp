@@ -1,0 +1,502 @@
+// nmpc_block.hpp -- parallel-in-time Riccati factorisation of one active-set pass (gfx950 device code).
+//
+// What it is for: at N = 600 (cfg/rotors_mpc.cfg:9 allows it; controller.py:184 then asks HPIPM for partial condensing into
+// qp_solver_cond_N = 5 blocks of 120 stages) one Riccati factorisation is 600 dependent stages, and the instances a long-horizon
+// solve leaves to the work list (~100 of 1024) keep 25 waves of a 1024-SIMD machine busy for 0.8 ms per pass.  Condensing a block
+// into one stage with 480 inputs - what the reference's CPU solver does - would trade that depth for a 480 x 480 Cholesky per
+// block and iteration.  On this machine the blocks pay as PARALLELISM instead: the horizon is cut into J blocks, every block is
+// swept by its own team at the same time, and only J small boundary updates stay sequential.
+//
+// The algebra (tools/dev/block_riccati_model.py holds it in numpy).  Stage k of the pinned LQ problem, in the padded homogeneous
+// form of nmpc_team_as.hpp (xbar = (x, 1): the stage gradient sits in row / column 15 of Qbar, b_k and the pinned inputs in column 15
+// of Abar, the input gradient in column 15 of X):
+//     H = D + Bm'P Bm = L Dh L',   X = Bm'P Abar + rhat e15',   M0 = L^-1 X,   M = Dh^-1 M0,   P_k = Qbar + Abar'P Abar - M0'M
+// is a linear-fractional map of the value P behind it.  For a block [s, e) the composition of its stage maps is
+//     P_s = J + Psi' T Psi,      T = P_e (I + C P_e)^-1,
+// where J is the result of the ordinary sweep started from P_e = 0, Psi the product of that sweep's closed-loop transitions
+// Abar - Bm Kbar and C = sum_k (Psi_{k+1} Bm) H^-1 (Psi_{k+1} Bm)' their controllability Gramian weighted by H^-1 (the combination
+// rule of Sarkka & Garcia-Fernandez, "Temporal parallelization of dynamic programming and linear quadratic control", restated for a
+// backward sweep: with C1 = Bm D^-1 Bm' the Woodbury identity turns every (I + C1 J2)^-1 of that rule into the 4 x 4 factorisation
+// the stage performs anyway).  So:
+//   launch 1  k_block_sweep   blocks 0 .. J-2: zero-terminal sweep carrying (J, Psi', C) - 84 MFMAs per stage on top of the 93 of the
+//                             factor stage; block J-1: the ordinary sweep from the terminal cost, factors stored
+//   launch 2  k_block_scan    one team per instance walks the J-1 interior boundaries: T through two 16 x 16 block L D L'
+//                             factorisations (T = L (Dp^-1 + L'C L)^-1 L' with P_e = L Dp L': symmetric positive definite
+//                             operations only, no cancellation; needs P_xx > 0, i.e. positive state weights)
+//   launch 3  k_block_sweep   blocks 0 .. J-2: the ordinary sweep from their boundary value, factors stored
+// The factors are the ones the sequential sweep of nmpc_team_as.hpp leaves (Mbar' tiles, L^-1 tile), equal to rounding times the
+// conditioning of the boundary update; tests/test_gpu_block.py compares them at N = 600.
+//
+// The stage below is the pins variant of sweepA's stage in nmpc_team_as.hpp (same products, same order), restated here because
+// that one is a lambda over the solver's pass state; nothing of this file is on the default solve path yet.
+#pragma once
+
+#include "nmpc_ipm.hpp"
+#include "nmpc_team.hpp"
+
+namespace nmpc {
+
+constexpr int BLK_FAC_ROWS = 80;     // factors of one stage: Mbar' as 4 tiles x 16 lanes (64) | L^-1 tile (16)
+constexpr int BLK_MAT = 256;         // a 16 x 16 matrix as 16 tiles x 16 lanes
+constexpr int BLK_LDS = 56;          // doubles of LDS per team (gradient row 16 | zero slot | pad | 4 x 4 exchange 16): 192 B past a bank row
+
+struct BlockWork {
+    const double *tAB;     // [Bp + 1][N][TAB_ROWS] stage tiles of the per-stage linearisation (left by the last solve)
+    const double *tIV;     // [Bp + 1][N][IV_ROWS]  slots 16..19: pin codes of the accepted pass
+    double *agg;           // [Bp + 1][J][3][256]   J | Psi' | C of block j (zero-terminal sweep)
+    double *bnd;           // [Bp + 1][J + 1][256]  value at the START of block j (bnd[J]: unused)
+    double *bchk;          // [Bp + 1][J + 1][256]  start value of block j as its own sweep of launch 3 recomputes it (diagnostic; may be null)
+    double *fac;           // [Bp + 1][N][80]       factors
+    int Bp, B, J, M;       // M = stages per block
+};
+
+#if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
+
+// H (4 x 4, symmetric, its lower triangle handed round through `ex`) = L Dh L' in every lane of the team: reciprocals of the
+// pivots, the tile of L^-T (lane (a,c): (L^-1)[c][a]) and, on request, the tile of L itself.  forced_last: the last pivot is
+// replaced by 1 (the constant of a value function).  ok: cleared by a pivot that is not positive.
+struct Ldl4 {
+    double r0, r1, r2, r3, Y, Lt;
+};
+template <bool WANT_L>
+__device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool forced_last, bool &ok)
+{
+    using T = double;
+    if (tc <= ta) ex[lidx(ta, tc)] = h;
+    NMPC_WSYNC();
+    T Lf[10];
+    NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = ex[i];
+    NMPC_WSYNC();
+    const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
+    const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
+    auto pivot = [&](T d) -> T {
+        const bool pos = d > T(0);
+        ok &= pos;
+        return fast_rcp(pos ? d : T(1));
+    };
+    Ldl4 o;
+    o.r0 = pivot(h00);
+    const T l10 = h10 * o.r0, l20 = h20 * o.r0, l30 = h30 * o.r0;
+    o.r1 = pivot(h11 - l10 * h10);
+    const T c21 = h21 - l20 * h10, c31 = h31 - l30 * h10;
+    const T l21 = c21 * o.r1, l31 = c31 * o.r1;
+    o.r2 = pivot(h22 - l20 * h20 - l21 * c21);
+    const T c32 = h32 - l30 * h20 - l31 * c21;
+    const T l32 = c32 * o.r2;
+    const T d3 = h33 - l30 * h30 - l31 * c31 - l32 * c32;
+    o.r3 = forced_last ? T(1) : pivot(d3);
+    {
+        const T i10 = -l10, i21 = -l21, i32 = -l32;
+        const T i20 = -(l20 + l21 * i10);
+        const T i31 = -(l31 + l32 * i21);
+        const T i30 = -(l30 + l31 * i10 + l32 * i20);
+        const int e = tc * 4 + ta;           // (row c, column a) of L^-1
+        T Y = (ta == tc) ? T(1) : T(0);
+        Y = e == 4 ? i10 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
+        Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y;
+        o.Y = Y;
+    }
+    o.Lt = 0;
+    if (WANT_L) {
+        const int e = ta * 4 + tc;           // (row a, column c) of L
+        T L = (ta == tc) ? T(1) : T(0);
+        L = e == 4 ? l10 : L;  L = e == 8 ? l20 : L;  L = e == 9 ? l21 : L;
+        L = e == 12 ? l30 : L; L = e == 13 ? l31 : L; L = e == 14 ? l32 : L;
+        o.Lt = L;
+    }
+    return o;
+}
+
+// One block [s, e) of one instance per team, swept backwards.
+//   AGG:  from P_e = 0, carrying Psi' and C; leaves (J, Psi', C) in agg          (launch 1, blocks 0 .. J-2)
+//   !AGG: from the terminal cost (e = N) or from bnd[blk + 1]; leaves the factors of its stages and its start value in bnd[blk]
+template <bool AGG, class TI>
+__device__ __forceinline__ void block_sweep(const Consts<double> &c, const BlockWork &g, const Inputs<TI> &in, int blk, double *smem)
+{
+    using T = double;
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
+    const int ta = r >> 2, tc = r & 3, j = tc;
+    const int rr = r < NX ? r : NX - 1;
+    int inst = blockIdx.x * 4 + team;
+    const bool valid = inst < g.B;
+    if (!valid) inst = g.B - 1;                       // idle teams read the last instance and write the spare row
+    const size_t winst = valid ? (size_t)inst : (size_t)g.Bp;
+    const int N = c.N;
+    const int s = blk * g.M, e = (s + g.M < N) ? s + g.M : N;
+    T *S = smem + team * BLK_LDS;
+    T *sh = S, *sHg = S + 24;
+    const bool warm = in.x_init != nullptr && in.u_init != nullptr;
+    const TI *x0p = in.x0 + (size_t)inst * NX;
+    const TI *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
+    const TI *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
+    const TI *xi = warm ? in.x_init + (size_t)inst * (N + 1) * NX : x0p;
+    const TI *ui = warm ? in.u_init + (size_t)inst * N * NU : x0p;
+    const T *tAB = g.tAB + (size_t)inst * N * TAB_ROWS;
+    const T *tIV = g.tIV + (size_t)inst * N * IV_ROWS;
+    T *fac = g.fac + winst * N * BLK_FAC_ROWS;
+
+    int natR[4], natC[4];
+    NMPC_UNROLL for (int t = 0; t < 4; t++) { natR[t] = nat_of(t, ta); natC[t] = nat_of(t, tc); }
+    T dt_v = c.dt;
+    asm volatile("" : "+v"(dt_v));
+    const T x0r = (T)x0p[rr];
+    const T Wq_r = c.Wq[rr], WqN_r = c.WqN[rr];
+    const T Wr_a = c.Wr[ta];
+    const T lbj = c.lbu[j], ubj = c.ubu[j];
+    const T lb_a = c.lbu[ta], ub_a = c.ubu[ta], Rd_a = c.Rd[ta];
+    T Qdg[4];
+    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+        const T qd = c.Qd[natR[t] >= 0 ? natR[t] : 0];
+        Qdg[t] = (ta == tc && natR[t] >= 0) ? qd : T(0);
+    }
+    constexpr int ZSLOT = 16;
+    int iq_col[4], iq_row[4];
+    NMPC_UNROLL for (int t = 0; t < 4; t++) {
+        iq_col[t] = (tc == 3 && natR[t] >= 0) ? natR[t] : ZSLOT;
+        iq_row[t] = (ta == 3 && natC[t] >= 0) ? natC[t] : ZSLOT;
+    }
+    if (r == 0) sh[ZSLOT] = T(0);
+    const T Idt = (ta == tc) ? T(1) : T(0);
+    auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
+    auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
+    T pfs[12];
+    auto fetch_stage = [&](int k) {
+        const T *a = tAB + (size_t)k * TAB_ROWS + r;
+        NMPC_UNROLL for (int t = 0; t < 12; t++) pfs[t] = (t == 9) ? T(0) : a[t * 16];      // tile (3,0) is zero and never stored
+    };
+
+    T Pt[4][4];
+    if (AGG) {
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = T(0);
+        }
+    } else if (e == N) {
+        // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
+        sh[r] = WqN_r * (xlin(N) - (T)ye[rr]);
+        NMPC_WSYNC();
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                T v = (it == jt && ta == tc && natR[it] >= 0) ? c.QdN[natR[it] >= 0 ? natR[it] : 0] : T(0);
+                const T qa = sh[natR[it] >= 0 ? natR[it] : 0], qb = sh[natC[jt] >= 0 ? natC[jt] : 0];
+                if (jt == 3 && tc == 3 && natR[it] >= 0) v = qa;
+                if (it == 3 && ta == 3 && natC[jt] >= 0) v = qb;
+                Pt[it][jt] = v;
+            }
+        }
+        NMPC_WSYNC();
+    } else {
+        const T *bp = g.bnd + (winst * (g.J + 1) + blk + 1) * BLK_MAT + r;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pt[it][jt] = bp[(it * 4 + jt) * 16];
+        }
+    }
+    // Phi = Psi' (tile (kt,it) of Phi is the transpose of tile (it,kt) of Psi) and C, upper tiles
+    T Ph[AGG ? 4 : 1][AGG ? 4 : 1], Cm[AGG ? 4 : 1][AGG ? 4 : 1];
+    if (AGG) {
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                Ph[it][jt] = (it == jt && ta == tc && (natR[it] >= 0 || (it == 3 && ta == 3))) ? T(1) : T(0);
+                Cm[it][jt] = T(0);
+            }
+        }
+    }
+    bool ok = true;
+    int ks = e - 1;
+    fetch_stage(ks);
+    T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + ta];
+    T n_xl = xlin(ks), n_ul = ulin(ks, ta);
+    T n_pc = tIV[ks * IV_ROWS + 16 + j], n_pca = tIV[ks * IV_ROWS + 16 + ta], n_ulc = ulin(ks, j);
+    for (int k = ks; k >= s; k--) {
+        T Aq0[4], Aq1[4], Bt[4];
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
+        const int kn = k > s ? k - 1 : s;                   // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
+        fetch_stage(kn);
+        const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc;
+        T rk = Wr_a * (ul - n_yu);
+        const T q_r = Wq_r * (n_xl - n_yx);
+        asm volatile("" : "+v"(rk));
+        n_yx = (T)yr[(size_t)kn * NY + rr]; n_yu = (T)yr[(size_t)kn * NY + NX + ta];
+        n_xl = xlin(kn); n_ul = ulin(kn, ta);
+        n_pc = tIV[kn * IV_ROWS + 16 + j]; n_pca = tIV[kn * IV_ROWS + 16 + ta]; n_ulc = ulin(kn, j);
+        sh[r] = q_r;
+        // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps R_jj so that u_j = bound
+        const bool pinned_a = pca != T(0), pinned = pc != T(0);
+        const T vpin_a = pca < T(0) ? lb_a - ul : ub_a - ul;
+        const T vpin_c = pc < T(0) ? lbj - ulc : ubj - ulc;
+        const T mask_a = pinned_a ? T(0) : T(1), mask_c = pinned ? T(0) : T(1);
+        const T rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
+        if (__ballot(pinned) != 0) {
+            const T vp = pinned ? vpin_c : T(0);
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                const T sm = quad_sum(Bt[kt] * vp);
+                if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
+            }
+        }
+        T WB[4], Hr = 0;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            T aB = 0;
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
+            WB[it] = aB;
+        }
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
+        const T Huu = ((ta == tc) ? Rd_a : T(0)) + mask_a * mask_c * Hr;
+        T W0[4], W1[4];
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            T a0 = 0, a1 = 0;
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
+                a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
+            }
+            W0[it] = a0; W1[it] = a1;
+        }
+        T PA[4][4];
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+            PA[kt][0] = Pt[kt][0];
+            PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
+            PA[kt][2] = W0[kt];
+            PA[kt][3] = W1[kt];
+        }
+        T X0raw = 0, X[4];
+        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+            T a = 0;
+            if (jt == 0) a = mfma44(WB[0], Idt, T(0));
+            else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
+            else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
+            if (jt == 0) X0raw = a;
+            X[jt] = mask_a * a;
+        }
+        if (tc == 3) X[3] += rhat_a;
+        T Pn[4][4];
+        {
+            T qcol[4], qrow[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
+                T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
+                if (jt >= 2) {
+                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                        if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
+                        if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
+                    }
+                }
+                Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
+                Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
+                Pn[2][jt] = a2;
+                Pn[3][jt] = a3;
+            }
+        }
+        const Ldl4 f = ldl4<false>(Huu, sHg, ta, tc, false, ok);
+        const T Y = f.Y;
+        const T ra = ta == 0 ? f.r0 : (ta == 1 ? f.r1 : (ta == 2 ? f.r2 : f.r3));
+        T M0[4], M[4];
+        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+            M0[jt] = mfma44(Y, X[jt], T(0));
+            M[jt] = ra * M0[jt];
+        }
+        if (!AGG) {
+            T *fk = fac + (size_t)k * BLK_FAC_ROWS;
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) fk[jt * 16 + tc * 4 + ta] = M[jt];        // where a forward sweep reads it transposed
+            fk[64 + r] = mfma44(Y, Idt, T(0));                                                  // Y' = L^-1 as a tile
+        }
+        if (AGG) {
+            // G' = Bm' Phi (rows of pinned inputs masked), N0 = L^-1 G', Nn = Dh^-1 N0:  C += N0' Nn,  Phi <- Abar' Phi - M' N0
+            T N0[4], Nn[4];
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                T gt = 0;
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) gt = mfma44(Bt[kt], Ph[kt][it], gt);
+                N0[it] = mfma44(Y, mask_a * gt, T(0));
+                Nn[it] = ra * N0[it];
+            }
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = it; jt < 4; jt++) Cm[it][jt] = mfma44(N0[it], Nn[jt], Cm[it][jt]);
+            }
+            T Pq[4][4];
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                T a2 = 0, a3 = 0;
+                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
+                    if (kt < 3) a2 = mfma44(Aq0[kt], Ph[kt][it], a2);
+                    a3 = mfma44(Aq1[kt], Ph[kt][it], a3);
+                }
+                Pq[0][it] = Ph[0][it];
+                Pq[1][it] = dt_v * Ph[0][it] + Ph[1][it];
+                Pq[2][it] = a2;
+                Pq[3][it] = a3;
+            }
+            T Mneg[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) Mneg[t] = -M[t];
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) Ph[jt][it] = mfma44(Mneg[jt], N0[it], Pq[jt][it]);
+            }
+        }
+        {
+            T Mn[4];
+            NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
+            }
+            NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
+            NMPC_UNROLL for (int it = 1; it < 4; it++) {
+                NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
+            }
+        }
+        NMPC_WSYNC();
+    }
+    if (AGG) {
+        NMPC_UNROLL for (int it = 0; it < 4; it++) Cm[it][it] = T(0.5) * (Cm[it][it] + mfma44(Cm[it][it], Idt, T(0)));
+        NMPC_UNROLL for (int it = 1; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < it; jt++) Cm[it][jt] = mfma44(Cm[jt][it], Idt, T(0));
+        }
+        T *ap = g.agg + (winst * g.J + blk) * 3 * BLK_MAT + r;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                ap[(it * 4 + jt) * 16] = ok ? Pt[it][jt] : __builtin_nan("");
+                ap[BLK_MAT + (it * 4 + jt) * 16] = Ph[it][jt];
+                ap[2 * BLK_MAT + (it * 4 + jt) * 16] = Cm[it][jt];
+            }
+        }
+    } else {
+        // start value of the block: the last block hands it to the scan; the others (launch 3) must not touch bnd - their
+        // neighbours are reading it - and leave theirs in the diagnostic copy, where it can be compared with the scan's
+        T *bb = e == N ? g.bnd : g.bchk;
+        if (bb) {
+            T *bp = bb + (winst * (g.J + 1) + blk) * BLK_MAT + r;
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) bp[(it * 4 + jt) * 16] = ok ? Pt[it][jt] : __builtin_nan("");
+            }
+        }
+    }
+}
+
+// 16 x 16 symmetric positive definite A (upper tiles Au[i][k], k >= i; consumed) = L D L' by tiles: per tile column j the
+// 4 x 4 factorisation of the diagonal tile, LT[j][i] = L_ij' (i > j), the tiles of the diagonal blocks L_jj and L_jj^-T, 1 / d.
+struct Ldl16 {
+    double LT[4][4];      // [j][i], i > j: (L_ij)'
+    double Ld[4];         // L_jj as a tile
+    double Yd[4];         // L_jj^-T as a tile
+    double ra[4], rc[4];  // 1 / d of tile column j by the lane's row a | column c
+};
+__device__ __forceinline__ void ldl16(double (&Au)[4][4], Ldl16 &o, double *ex, int ta, int tc, bool forced_last, bool &ok)
+{
+    using T = double;
+    NMPC_UNROLL for (int jc = 0; jc < 4; jc++) {
+        const Ldl4 f = ldl4<true>(Au[jc][jc], ex, ta, tc, forced_last && jc == 3, ok);
+        o.Ld[jc] = f.Lt; o.Yd[jc] = f.Y;
+        o.ra[jc] = ta == 0 ? f.r0 : (ta == 1 ? f.r1 : (ta == 2 ? f.r2 : f.r3));
+        o.rc[jc] = tc == 0 ? f.r0 : (tc == 1 ? f.r1 : (tc == 2 ? f.r2 : f.r3));
+        T UT[4];
+        NMPC_UNROLL for (int i = 0; i < 4; i++) {
+            if (i > jc) {
+                UT[i] = mfma44(f.Y, Au[jc][i], T(0));          // L_jj^-1 A_ji = D_j L_ij'
+                o.LT[jc][i] = o.ra[jc] * UT[i];
+            }
+        }
+        NMPC_UNROLL for (int i = 0; i < 4; i++) {
+            NMPC_UNROLL for (int k = i; k < 4; k++) {
+                if (i > jc) Au[i][k] = mfma44(-UT[i], o.LT[jc][k], Au[i][k]);     // A_ik -= L_ij D_j L_kj'
+            }
+        }
+    }
+}
+
+// launch 2: the interior boundaries of one instance, last to first:  P_s = J + Psi' T Psi,  T = L (Dp^-1 + L'C L)^-1 L'
+__device__ __forceinline__ void block_scan(const BlockWork &g, double *smem)
+{
+    using T = double;
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
+    const int ta = r >> 2, tc = r & 3;
+    const int rT = tc * 4 + ta;
+    int inst = blockIdx.x * 4 + team;
+    const bool valid = inst < g.B;
+    const size_t winst = valid ? (size_t)inst : (size_t)g.Bp;
+    T *ex = smem + team * BLK_LDS + 24;
+    const T Idt = (ta == tc) ? T(1) : T(0);
+    T Pe[4][4];
+    {
+        const T *bp = g.bnd + (winst * (g.J + 1) + g.J - 1) * BLK_MAT + r;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pe[it][jt] = bp[(it * 4 + jt) * 16];
+        }
+    }
+    for (int blk = g.J - 2; blk >= 0; blk--) {
+        const T *ap = g.agg + (winst * g.J + blk) * 3 * BLK_MAT;
+        bool ok = true;
+        // P_e with unit pads (positions 3 and 7 of the padded state carry nothing) = L Dp L', the constant's pivot forced to 1
+        T Au[4][4];
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = it; jt < 4; jt++) Au[it][jt] = Pe[it][jt] + ((it == jt && it < 2 && ta == 3 && tc == 3) ? T(1) : T(0));
+        }
+        Ldl16 lp;
+        ldl16(Au, lp, ex, ta, tc, true, ok);
+        // tiles of L: Lm[m][k], m >= k
+        T Lm[4][4];
+        NMPC_UNROLL for (int k = 0; k < 4; k++) {
+            Lm[k][k] = lp.Ld[k];
+            NMPC_UNROLL for (int m = k + 1; m < 4; m++) Lm[m][k] = mfma44(lp.LT[k][m], Idt, T(0));
+        }
+        // E = Dp^-1 + L' C L (upper tiles): F = C L, E = L' F
+        T E[4][4];
+        {
+            T Cf[4][4];
+            NMPC_UNROLL for (int it = 0; it < 4; it++) {
+                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Cf[it][jt] = ap[2 * BLK_MAT + (it * 4 + jt) * 16 + r];
+            }
+            T F[4][4];
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {
+                NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                    T a = 0;
+                    NMPC_UNROLL for (int m = k; m < 4; m++) a = mfma44(Cf[m][i], Lm[m][k], a);
+                    F[i][k] = a;
+                }
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {
+                NMPC_UNROLL for (int k = i; k < 4; k++) {
+                    T a = (i == k && ta == tc) ? lp.ra[i] : T(0);
+                    // the pivots the factorisation replaced: 1 / d of a pad is 1, of the constant 1 (forced)
+                    NMPC_UNROLL for (int m = i; m < 4; m++) a = mfma44(Lm[m][i], F[m][k], a);
+                    E[i][k] = a;
+                }
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) E[i][i] = T(0.5) * (E[i][i] + mfma44(E[i][i], Idt, T(0)));
+        }
+        Ldl16 le;
+        ldl16(E, le, ex, ta, tc, false, ok);
+        // Z = Le^-1 (L' Psi), rows of tiles by forward substitution; Psi = Phi' is read through the transposed lane index
+        T Z[4][4];
+        {
+            T Ps[4][4];
+            NMPC_UNROLL for (int n = 0; n < 4; n++) {
+                NMPC_UNROLL for (int k = 0; k < 4; k++) Ps[n][k] = ap[BLK_MAT + (k * 4 + n) * 16 + rT];
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {
+                NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                    T a = 0;
+                    NMPC_UNROLL for (int n = i; n < 4; n++) a = mfma44(Lm[n][i], Ps[n][k], a);         // (L' Psi)[i][k]
+                    NMPC_UNROLL for (int m = 0; m < 4; m++) {
+                        if (m < i) a = mfma44(-le.LT[m][i], Z[m][k], a);                               // - Le_im Z[m][k]
+                    }
+                    Z[i][k] = mfma44(le.Yd[i], a, T(0));
+                }
+            }
+        }
+        // P_s = J + Z' De^-1 Z
+        NMPC_UNROLL for (int k = 0; k < 4; k++) {
+            NMPC_UNROLL for (int l = k; l < 4; l++) {
+                T a = ap[(k * 4 + l) * 16 + r];
+                NMPC_UNROLL for (int i = 0; i < 4; i++) a = mfma44(Z[i][k], le.ra[i] * Z[i][l], a);
+                Pe[k][l] = a;
+            }
+        }
+        NMPC_UNROLL for (int it = 0; it < 4; it++) Pe[it][it] = T(0.5) * (Pe[it][it] + mfma44(Pe[it][it], Idt, T(0)));
+        NMPC_UNROLL for (int it = 1; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pe[it][jt] = mfma44(Pe[jt][it], Idt, T(0));
+        }
+        T *bp = g.bnd + (winst * (g.J + 1) + blk) * BLK_MAT + r;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) bp[(it * 4 + jt) * 16] = ok ? Pe[it][jt] : __builtin_nan("");
+        }
+    }
+}
+
+#endif  // device
+
+}  // namespace nmpc

@@ -22,6 +22,7 @@
 #include "nmpc_team.hpp"
 #include "nmpc_team_as.hpp"
 #include "nmpc_as_launch.hpp"
+#include "nmpc_block_launch.hpp"
 #include "nmpc_cond.hpp"
 #include "nmpc_aux.hpp"
 #include "nmpc_consts.hpp"
@@ -143,6 +144,10 @@ struct nmpc_solver {
     std::vector<double> sx, su, syref, syref_e, sx0;
     std::vector<float> cvt;   // FP32 conversions of the host-buffer entry point
     std::vector<double> sxo, suo;   // result slot of nmpc_solve (swapped in on success)
+    // parallel-in-time factorisation (nmpc_block.hpp): buffers grown on demand
+    double *blk_agg = nullptr, *blk_bnd = nullptr, *blk_chk = nullptr, *blk_fac = nullptr;
+    int blk_J = 0;
+    hipEvent_t blk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
@@ -374,6 +379,10 @@ void nmpc_destroy(nmpc_solver *s)
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
+    for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac})
+        if (p) (void)hipFree(p);
+    for (auto &e : s->blk_ev)
+        if (e) (void)hipEventDestroy(e);
     if (s->d_in) (void)hipFree(s->d_in);
     if (s->d_out) (void)hipFree(s->d_out);
     if (s->h_in) (void)hipHostFree(s->h_in);
@@ -974,6 +983,82 @@ int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void
                            (const float *)yref_e, yref_bcast, (float *)res);
     }
     HIP_TRY(s, hipGetLastError());
+    return 0;
+}
+
+// Parallel-in-time Riccati factorisation (nmpc_block.hpp) of the LQ problem the LAST solve of this handle ended on: its
+// per-stage linearisation (stage tiles in the workspace) and the pin set its last forward sweep left.
+int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, const void *yref, const void *yref_e, int yref_bcast,
+                             const void *x_init, const void *u_init, double *factors_out, double *boundary_out, double *check_out,
+                             float *ms_out, void *hip_stream)
+{
+    if (!s) return NMPC_EARG;
+    const int N = s->cfg.N;
+    if (B < 1 || B > s->cfg.max_batch || !x0 || !yref || !yref_e) return s->fail(NMPC_EARG, "block_factor: bad arguments");
+    if (blocks < 1 || blocks > N) return s->fail(NMPC_EARG, "block_factor: blocks=%d outside [1, N=%d]", blocks, N);
+    if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "block_factor: x_init and u_init must both be given or both be NULL");
+    if (s->cfg.dtype == NMPC_DTYPE_F32 || !(s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) || (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) || !s->tAB)
+        return s->fail(NMPC_EARG, "block_factor: FP64 arithmetic in the team mapping only");
+    if (!s->solved || s->last_B < B) return s->fail(NMPC_EARG, "block_factor: no solve of >= %d instances on this handle yet", B);
+    if (x_init == nullptr && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START))
+        return s->fail(NMPC_EARG, "block_factor: needs the per-stage linearisation (a warm start, or NMPC_FLAG_SHARE_COLD_START off)");
+    if (s->cfg.sim_num_steps > AS_MAX_STEPS) return s->fail(NMPC_EARG, "block_factor: sim_num_steps > %d is not built", AS_MAX_STEPS);
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    hipStream_t st = (hipStream_t)hip_stream;
+    const int J = blocks, M = (N + J - 1) / J;
+    const int Jeff = (N + M - 1) / M;            // blocks that actually hold stages
+    const size_t Bw = (size_t)s->Bp + 1;
+    if (Jeff > s->blk_J || !s->blk_fac) {
+        for (double **p : {&s->blk_agg, &s->blk_bnd, &s->blk_chk, &s->blk_fac})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        s->blk_J = 0;
+        HIP_TRY(s, hipMalloc((void **)&s->blk_agg, Bw * Jeff * 3 * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, hipMalloc((void **)&s->blk_bnd, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, hipMalloc((void **)&s->blk_chk, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, hipMalloc((void **)&s->blk_fac, Bw * (size_t)N * BLK_FAC_ROWS * sizeof(double)));
+        s->blk_J = Jeff;
+        for (auto &e : s->blk_ev)
+            if (!e) HIP_TRY(s, hipEventCreate(&e));
+    }
+    BlockLaunch bl;
+    bl.cp = (const Consts<double> *)s->d_consts;
+    bl.g.tAB = (const double *)s->tAB; bl.g.tIV = (const double *)s->iv;
+    bl.g.agg = s->blk_agg; bl.g.bnd = s->blk_bnd; bl.g.bchk = check_out ? s->blk_chk : nullptr; bl.g.fac = s->blk_fac;
+    bl.g.Bp = s->Bp; bl.g.B = B; bl.g.J = Jeff; bl.g.M = M;
+    bl.stream = st; bl.timing = ms_out != nullptr;
+    for (int i = 0; i < 4; i++) bl.ev[i] = s->blk_ev[i];
+    if (s->cfg.dtype == NMPC_DTYPE_F32IO) {
+        Inputs<float> in;
+        in.x0 = (const float *)x0; in.yref = (const float *)yref; in.yref_e = (const float *)yref_e;
+        in.x_init = (const float *)x_init; in.u_init = (const float *)u_init; in.yref_bcast = yref_bcast;
+        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+    } else {
+        Inputs<double> in;
+        in.x0 = (const double *)x0; in.yref = (const double *)yref; in.yref_e = (const double *)yref_e;
+        in.x_init = (const double *)x_init; in.u_init = (const double *)u_init; in.yref_bcast = yref_bcast;
+        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+    }
+    if (factors_out) HIP_TRY(s, hipMemcpyAsync(factors_out, s->blk_fac, (size_t)B * N * BLK_FAC_ROWS * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (boundary_out) HIP_TRY(s, hipMemcpyAsync(boundary_out, s->blk_bnd, (size_t)B * (Jeff + 1) * BLK_MAT * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (check_out) HIP_TRY(s, hipMemcpyAsync(check_out, s->blk_chk, (size_t)B * (Jeff + 1) * BLK_MAT * sizeof(double), hipMemcpyDeviceToDevice, st));
+    if (ms_out) {
+        HIP_TRY(s, hipEventSynchronize(s->blk_ev[3]));
+        for (int i = 0; i < 3; i++) HIP_TRY(s, hipEventElapsedTime(&ms_out[i], s->blk_ev[i], s->blk_ev[i + 1]));
+    }
+    return Jeff;
+}
+
+// The factors (Mbar' tiles | L^-1 tile: 80 doubles per stage) the last solve's own factor sweeps left in the workspace, to the HOST:
+// [B][N][80].  Complete only when the solve ran without the LDS stage cache (NMPC_TEAM_LSTG=0): cached stages never reach HBM.
+int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || B > s->Bp || !host_out) return s->fail(NMPC_EARG, "debug_factors: bad arguments");
+    if (s->wsz != 8) return s->fail(NMPC_EARG, "debug_factors: FP64 workspace only");
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    HIP_TRY(s, hipDeviceSynchronize());
+    HIP_TRY(s, hipMemcpy2D(host_out, BLK_FAC_ROWS * sizeof(double), (const double *)s->LM + TLM_MT, TLM_ROWS * sizeof(double),
+                           BLK_FAC_ROWS * sizeof(double), (size_t)B * s->cfg.N, hipMemcpyDeviceToHost));
     return 0;
 }
 

@@ -167,6 +167,25 @@ class NmpcOcpSolver:
         self._check(self._lib.nmpc_kkt_report_device(self._h, int(B), x_traj_ptr, u_traj_ptr, yref_ptr, yref_e_ptr,
                                                      int(bool(yref_bcast)), res_ptr, stream or None))
 
+    def block_factor_device(self, B: int, blocks: int, x0_ptr: int, yref_ptr: int, yref_e_ptr: int, yref_bcast: bool,
+                            x_init_ptr: int = 0, u_init_ptr: int = 0, factors_ptr: int = 0, boundary_ptr: int = 0,
+                            check_ptr: int = 0, timed: bool = False, stream: int = 0):
+        """Parallel-in-time Riccati factorisation of the LQ problem the last solve ended on (include/rotors_nmpc.h,
+        nmpc_block_factor_device).  Returns (J, (ms_launch1, ms_scan, ms_launch3) or None)."""
+        ms = (C.c_float * 3)() if timed else None
+        rc = self._lib.nmpc_block_factor_device(self._h, int(B), int(blocks), x0_ptr, yref_ptr, yref_e_ptr, int(bool(yref_bcast)),
+                                                x_init_ptr or None, u_init_ptr or None, factors_ptr or None, boundary_ptr or None,
+                                                check_ptr or None, ms, stream or None)
+        if rc < 0:
+            self._check(rc)
+        return rc, (tuple(ms) if timed else None)
+
+    def debug_factors(self, B: int) -> np.ndarray:
+        """[B][N][80] factors the last solve's own sweeps left in the workspace (complete only with NMPC_TEAM_LSTG=0)."""
+        out = np.empty((int(B), self.config.N, 80))
+        self._check(self._lib.nmpc_debug_factors(self._h, int(B), out.ctypes.data_as(C.POINTER(C.c_double))))
+        return out
+
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 
