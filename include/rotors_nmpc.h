@@ -280,6 +280,11 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
  * complete only for a solve that ran without the LDS stage cache, NMPC_TEAM_LSTG=0) */
 int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out);
 
+/* diagnostic: where the block-parallel tail of long-horizon solves (csrc/nmpc_block.hpp) left the instances
+ * of the last solve: host_out [B] = 0 not in the work list, 3 finished by the tail, 5 handed on to the sequential work-list kernel.
+ * Returns the number of blocks the tail cuts the horizon into (0: this handle runs no tail - N < 256 unless NMPC_BLOCK_TAIL=1) */
+int nmpc_debug_tail_states(nmpc_solver *s, int B, int32_t *host_out);
+
 /* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */
 const char *nmpc_version(void);
 

@@ -17,7 +17,9 @@ struct AsLaunch {
     WorkList wl;
     int B, tpw, lds_stride, lstg, occ;
     int lm_off = 0;             // LDS offset (doubles) of a team's stage cache behind its working arrays
-    int kind = 0;               // 0: k_team_as (first attempt), 1: k_team_qp (whole QP, whole batch), 2: k_team_qp_list (work list)
+    int kind = 0;               // 0: k_team_as (first attempt), 1: k_team_qp (whole QP, whole batch), 2: k_team_qp_list (work list),
+                                // 3: k_team_tail (one step of the block-parallel tail), 4: reset of a work list
+    TailCtx tail;               // kind 3
     int nlist = 0;              // workgroups of the work-list launch
     bool shared, traj;
     size_t lds_bytes;

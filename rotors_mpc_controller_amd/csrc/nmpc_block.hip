@@ -14,14 +14,60 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep(const Consts<double> *__r
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
     const int blk = blockIdx.y;
-    if (phase == 1 && blk < g.J - 1) block_sweep<true, TI>(*cp, g, in, blk, smem);
-    else block_sweep<false, TI>(*cp, g, in, blk, smem);
+    const int team = (threadIdx.x >> 2) & 3;
+    int inst = blockIdx.x * 4 + team;
+    const bool valid = inst < g.B;
+    if (!valid) inst = g.B - 1;                       // idle teams read the last instance and write the spare row
+    if (phase == 1 && blk < g.J - 1) block_sweep<true, TI>(*cp, g, in, blk, smem, inst, valid);
+    else block_sweep<false, TI>(*cp, g, in, blk, smem, inst, valid);
 }
 
 __global__ __launch_bounds__(64, 1) void k_block_scan(BlockWork g)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
-    block_scan(g, smem);
+    const int team = (threadIdx.x >> 2) & 3;
+    const int inst = blockIdx.x * 4 + team;
+    block_scan(g, smem, inst < g.B ? inst : g.B - 1, inst < g.B);
+}
+
+// The same three launches for the work list of a long-horizon solve (tail mode): a fixed grid strides over the list; what a team
+// factorises - pins of an active-set pass or barrier terms of an interior-point iteration - is its instance's tail state
+__device__ __forceinline__ bool tail_pick(const BlockWork &g, int base, int n, int &inst)
+{
+    const int team = (threadIdx.x >> 2) & 3;
+    const int e = base + team;
+    int i = g.list[e < n ? e : base];
+    const int st = (int)g.ts[(size_t)i * TS_ROWS];
+    const bool act = e < n && (st == TS_IPM || st == TS_AS);
+    inst = i;
+    return act;
+}
+template <class TI>
+__global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double> *__restrict__ cp, BlockWork g, Inputs<TI> in, int phase)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
+    const int blk = blockIdx.y;
+    const int n = *g.count;
+    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+        int inst;
+        const bool act = tail_pick(g, base, n, inst);
+        if (__ballot(act) == 0) continue;
+        if (phase == 1 && blk < g.J - 1) block_sweep<true, TI, true>(*cp, g, in, blk, smem, inst, act);
+        else block_sweep<false, TI, true>(*cp, g, in, blk, smem, inst, act);
+        __syncthreads();
+    }
+}
+__global__ __launch_bounds__(64, 1) void k_block_scan_tail(BlockWork g)
+{
+    __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
+    const int n = *g.count;
+    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+        int inst;
+        const bool act = tail_pick(g, base, n, inst);
+        if (__ballot(act) == 0) continue;
+        block_scan(g, smem, inst, act);
+        __syncthreads();
+    }
 }
 
 template <class TI>
@@ -29,6 +75,13 @@ int launch_impl(const BlockLaunch &a, const Inputs<TI> &in)
 {
     const BlockWork &g = a.g;
     const dim3 block(64);
+    if (a.tail_grid > 0) {
+        const unsigned gx = (unsigned)a.tail_grid;
+        hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)g.J), block, 0, a.stream, a.cp, g, in, 1);
+        hipLaunchKernelGGL(k_block_scan_tail, dim3(gx), block, 0, a.stream, g);
+        hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)(g.J - 1)), block, 0, a.stream, a.cp, g, in, 3);
+        return (int)hipGetLastError();
+    }
     const unsigned gx = (unsigned)((g.B + 3) / 4);
     if (a.timing) (void)hipEventRecord(a.ev[0], a.stream);
     hipLaunchKernelGGL((k_block_sweep<TI>), dim3(gx, (unsigned)g.J), block, 0, a.stream, a.cp, g, in, 1);

@@ -48,6 +48,14 @@ struct BlockWork {
     double *bchk;          // [Bp + 1][J + 1][256]  start value of block j as its own sweep of launch 3 recomputes it (diagnostic; may be null)
     double *fac;           // [Bp + 1][N][80]       factors
     int Bp, B, J, M;       // M = stages per block
+    // tail mode (the long-horizon work list): instances come from the work list, what is factorised is decided
+    // by the instance's tail state, factors go straight into the solver's own rows
+    const int *list;       // work list of the active-set kernel, *count entries
+    const int *count;
+    const double *ts;      // [Bp + 1][TS_ROWS] tail state (nmpc_team.hpp)
+    double *tLM;           // [Bp + 1][N][TLM_ROWS]
+    double *binfo;         // [Bp + 1][J][2] per block: max |B'PB| of the final sweep | 0 ok, 1 pivot not positive, 2 NaN pivot
+    int shared;            // one linearisation for all stages: tiles of stage 0
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -57,6 +65,7 @@ struct BlockWork {
 // replaced by 1 (the constant of a value function).  ok: cleared by a pivot that is not positive.
 struct Ldl4 {
     double r0, r1, r2, r3, Y, Lt;
+    bool nan;      // a pivot was NaN
 };
 template <bool WANT_L>
 __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool forced_last, bool &ok)
@@ -69,12 +78,13 @@ __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool 
     NMPC_WSYNC();
     const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
     const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
+    Ldl4 o;
+    o.nan = false;
     auto pivot = [&](T d) -> T {
         const bool pos = d > T(0);
-        ok &= pos;
+        ok &= pos; o.nan |= !(d == d);
         return fast_rcp(pos ? d : T(1));
     };
-    Ldl4 o;
     o.r0 = pivot(h00);
     const T l10 = h10 * o.r0, l20 = h20 * o.r0, l30 = h30 * o.r0;
     o.r1 = pivot(h11 - l10 * h10);
@@ -110,22 +120,23 @@ __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool 
 // One block [s, e) of one instance per team, swept backwards.
 //   AGG:  from P_e = 0, carrying Psi' and C; leaves (J, Psi', C) in agg          (launch 1, blocks 0 .. J-2)
 //   !AGG: from the terminal cost (e = N) or from bnd[blk + 1]; leaves the factors of its stages and its start value in bnd[blk]
-template <bool AGG, class TI>
-__device__ __forceinline__ void block_sweep(const Consts<double> &c, const BlockWork &g, const Inputs<TI> &in, int blk, double *smem)
+template <bool AGG, class TI, bool TAIL = false>
+__device__ __forceinline__ void block_sweep(const Consts<double> &c, const BlockWork &g, const Inputs<TI> &in, int blk, double *smem,
+                                            int inst, bool valid)
 {
+    // inst: an instance whose inputs may be read; valid: this team factorises it (idle teams sweep along in the spare row)
     using T = double;
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
     const int ta = r >> 2, tc = r & 3, j = tc;
     const int rr = r < NX ? r : NX - 1;
-    int inst = blockIdx.x * 4 + team;
-    const bool valid = inst < g.B;
-    if (!valid) inst = g.B - 1;                       // idle teams read the last instance and write the spare row
     const size_t winst = valid ? (size_t)inst : (size_t)g.Bp;
+    const bool ipm = TAIL && valid && (int)g.ts[(size_t)inst * TS_ROWS] == TS_IPM;     // barrier terms of an interior-point iteration instead of pins
     const int N = c.N;
     const int s = blk * g.M, e = (s + g.M < N) ? s + g.M : N;
     T *S = smem + team * BLK_LDS;
     T *sh = S, *sHg = S + 24;
-    const bool warm = in.x_init != nullptr && in.u_init != nullptr;
+    const bool shared = TAIL && g.shared != 0;
+    const bool warm = !shared && in.x_init != nullptr && in.u_init != nullptr;
     const TI *x0p = in.x0 + (size_t)inst * NX;
     const TI *yr = in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY;
     const TI *ye = in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX;
@@ -133,7 +144,8 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     const TI *ui = warm ? in.u_init + (size_t)inst * N * NU : x0p;
     const T *tAB = g.tAB + (size_t)inst * N * TAB_ROWS;
     const T *tIV = g.tIV + (size_t)inst * N * IV_ROWS;
-    T *fac = g.fac + winst * N * BLK_FAC_ROWS;
+    T *fac = TAIL ? nullptr : g.fac + winst * N * BLK_FAC_ROWS;
+    T *tLM = TAIL ? g.tLM + winst * N * TLM_ROWS : nullptr;
 
     int natR[4], natC[4];
     NMPC_UNROLL for (int t = 0; t < 4; t++) { natR[t] = nat_of(t, ta); natC[t] = nat_of(t, tc); }
@@ -160,7 +172,8 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
     auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
     T pfs[12];
-    auto fetch_stage = [&](int k) {
+    auto fetch_stage = [&](int kq) {
+        const int k = shared ? 0 : kq;
         const T *a = tAB + (size_t)k * TAB_ROWS + r;
         NMPC_UNROLL for (int t = 0; t < 12; t++) pfs[t] = (t == 9) ? T(0) : a[t * 16];      // tile (3,0) is zero and never stored
     };
@@ -192,7 +205,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     }
     // Phi = Psi' (tile (kt,it) of Phi is the transpose of tile (it,kt) of Psi) and C, upper tiles
     T Ph[AGG ? 4 : 1][AGG ? 4 : 1], Cm[AGG ? 4 : 1][AGG ? 4 : 1];
-    if (AGG) {
+    if constexpr (AGG) {
         NMPC_UNROLL for (int it = 0; it < 4; it++) {
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
                 Ph[it][jt] = (it == jt && ta == tc && (natR[it] >= 0 || (it == 3 && ta == 3))) ? T(1) : T(0);
@@ -206,26 +219,39 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + ta];
     T n_xl = xlin(ks), n_ul = ulin(ks, ta);
     T n_pc = tIV[ks * IV_ROWS + 16 + j], n_pca = tIV[ks * IV_ROWS + 16 + ta], n_ulc = ulin(ks, j);
+    T n_u = 0, n_ll = 0, n_lu = 0;                       // the iterate of input a (interior-point iteration)
+    if (TAIL) { n_u = tIV[ks * IV_ROWS + ta]; n_ll = tIV[ks * IV_ROWS + 4 + ta]; n_lu = tIV[ks * IV_ROWS + 8 + ta]; }
+    T gm = 0;
+    bool nanp = false;
     for (int k = ks; k >= s; k--) {
         T Aq0[4], Aq1[4], Bt[4];
         NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
         const int kn = k > s ? k - 1 : s;                   // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
         fetch_stage(kn);
-        const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc;
+        const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
         T rk = Wr_a * (ul - n_yu);
         const T q_r = Wq_r * (n_xl - n_yx);
         asm volatile("" : "+v"(rk));
         n_yx = (T)yr[(size_t)kn * NY + rr]; n_yu = (T)yr[(size_t)kn * NY + NX + ta];
         n_xl = xlin(kn); n_ul = ulin(kn, ta);
         n_pc = tIV[kn * IV_ROWS + 16 + j]; n_pca = tIV[kn * IV_ROWS + 16 + ta]; n_ulc = ulin(kn, j);
+        if (TAIL) { const T *ivn = tIV + kn * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
         sh[r] = q_r;
         // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps R_jj so that u_j = bound
-        const bool pinned_a = pca != T(0), pinned = pc != T(0);
+        const bool pinned_a = !ipm && pca != T(0), pinned = !ipm && pc != T(0);
         const T vpin_a = pca < T(0) ? lb_a - ul : ub_a - ul;
         const T vpin_c = pc < T(0) ? lbj - ulc : ubj - ulc;
         const T mask_a = pinned_a ? T(0) : T(1), mask_c = pinned ? T(0) : T(1);
-        const T rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
-        if (__ballot(pinned) != 0) {
+        T D_a = Rd_a, rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
+        if (TAIL) {
+            // barrier terms of the interior-point iteration: D = R + lam_l / t_l + lam_u / t_u, rhat = r - (D - R) u
+            const Pair<T> pr(u_it, ll_it, lu_it, lb_a - ul, ub_a - ul);
+            const T sg = pr.kl + pr.ku;
+            D_a = ipm ? Rd_a + sg : D_a;
+            rhat_a = ipm ? rk - sg * u_it : rhat_a;
+        }
+        const bool any_pins = __ballot(pinned) != 0;
+        if (any_pins) {
             const T vp = pinned ? vpin_c : T(0);
             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                 const T sm = quad_sum(Bt[kt] * vp);
@@ -239,7 +265,9 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
             WB[it] = aB;
         }
         NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
-        const T Huu = ((ta == tc) ? Rd_a : T(0)) + mask_a * mask_c * Hr;
+        const T Hrm = mask_a * mask_c * Hr;
+        if (!AGG) gm = fmax(gm, fabs(Hrm));              // growth certificate: max |B'PB| as the free inputs see it
+        const T Huu = ((ta == tc) ? D_a : T(0)) + Hrm;
         T W0[4], W1[4];
         NMPC_UNROLL for (int it = 0; it < 4; it++) {
             T a0 = 0, a1 = 0;
@@ -264,7 +292,10 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
             else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
             if (jt == 0) X0raw = a;
             X[jt] = mask_a * a;
+            // gradient rows of the pinned inputs for the multiplier check of the forward sweep
+            if (TAIL && !AGG) { if (any_pins) tLM[k * TLM_ROWS + TLM_G + jt * 16 + tc * 4 + ta] = a; }
         }
+        if (TAIL && !AGG) { if (any_pins) tLM[k * TLM_ROWS + TLM_G + 64 + tc * 4 + ta] = Hr; }
         if (tc == 3) X[3] += rhat_a;
         T Pn[4][4];
         {
@@ -286,6 +317,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
             }
         }
         const Ldl4 f = ldl4<false>(Huu, sHg, ta, tc, false, ok);
+        nanp |= f.nan;
         const T Y = f.Y;
         const T ra = ta == 0 ? f.r0 : (ta == 1 ? f.r1 : (ta == 2 ? f.r2 : f.r3));
         T M0[4], M[4];
@@ -294,11 +326,12 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
             M[jt] = ra * M0[jt];
         }
         if (!AGG) {
-            T *fk = fac + (size_t)k * BLK_FAC_ROWS;
+            T *fk = TAIL ? tLM + (size_t)k * TLM_ROWS + TLM_MT : fac + (size_t)k * BLK_FAC_ROWS;
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) fk[jt * 16 + tc * 4 + ta] = M[jt];        // where a forward sweep reads it transposed
             fk[64 + r] = mfma44(Y, Idt, T(0));                                                  // Y' = L^-1 as a tile
+            if (TAIL) tLM[(size_t)k * TLM_ROWS + TLM_RINV + ta + (tc == 0 ? 0 : 4)] = ra;        // 1 / d_a for the corrector's solves
         }
-        if (AGG) {
+        if constexpr (AGG) {
             // G' = Bm' Phi (rows of pinned inputs masked), N0 = L^-1 G', Nn = Dh^-1 N0:  C += N0' Nn,  Phi <- Abar' Phi - M' N0
             T N0[4], Nn[4];
             NMPC_UNROLL for (int it = 0; it < 4; it++) {
@@ -341,7 +374,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
         }
         NMPC_WSYNC();
     }
-    if (AGG) {
+    if constexpr (AGG) {
         NMPC_UNROLL for (int it = 0; it < 4; it++) Cm[it][it] = T(0.5) * (Cm[it][it] + mfma44(Cm[it][it], Idt, T(0)));
         NMPC_UNROLL for (int it = 1; it < 4; it++) {
             NMPC_UNROLL for (int jt = 0; jt < it; jt++) Cm[it][jt] = mfma44(Cm[jt][it], Idt, T(0));
@@ -357,6 +390,19 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     } else {
         // start value of the block: the last block hands it to the scan; the others (launch 3) must not touch bnd - their
         // neighbours are reading it - and leave theirs in the diagnostic copy, where it can be compared with the scan's
+        if (TAIL) {
+            // what the pass / iteration needs to know about this block's factorisation
+            sh[r] = gm;
+            NMPC_WSYNC();
+            T gt = sh[0];
+            NMPC_UNROLL for (int i = 1; i < 16; i++) gt = fmax(gt, sh[i]);
+            const unsigned long long team_mask = 0x000F000F000F000Full << (4 * team);
+            const bool t_bad = (__ballot(!ok) & team_mask) != 0, t_nan = (__ballot(nanp) & team_mask) != 0;
+            if (r == 0) {
+                T *bi = g.binfo + (winst * g.J + blk) * 2;
+                bi[0] = gt; bi[1] = t_nan ? T(2) : (t_bad ? T(1) : T(0));
+            }
+        }
         T *bb = e == N ? g.bnd : g.bchk;
         if (bb) {
             T *bp = bb + (winst * (g.J + 1) + blk) * BLK_MAT + r;
@@ -399,14 +445,12 @@ __device__ __forceinline__ void ldl16(double (&Au)[4][4], Ldl16 &o, double *ex, 
 }
 
 // launch 2: the interior boundaries of one instance, last to first:  P_s = J + Psi' T Psi,  T = L (Dp^-1 + L'C L)^-1 L'
-__device__ __forceinline__ void block_scan(const BlockWork &g, double *smem)
+__device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int inst, bool valid)
 {
     using T = double;
     const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);
     const int ta = r >> 2, tc = r & 3;
     const int rT = tc * 4 + ta;
-    int inst = blockIdx.x * 4 + team;
-    const bool valid = inst < g.B;
     const size_t winst = valid ? (size_t)inst : (size_t)g.Bp;
     T *ex = smem + team * BLK_LDS + 24;
     const T Idt = (ta == tc) ? T(1) : T(0);

@@ -14,6 +14,7 @@ struct BlockLaunch {
     hipStream_t stream;
     hipEvent_t ev[4];           // recorded around the three launches when non-null: [0] start, [1] after launch 1, [2] after the scan, [3] end
     bool timing;
+    int tail_grid = 0;          // > 0: tail mode (work list, factors into the solver's rows) with this many workgroups per block
 };
 
 // enqueue the factorisation (J = 1: one ordinary sweep per instance, the sequential form in the same code); returns a hipError_t

@@ -148,6 +148,12 @@ struct nmpc_solver {
     double *blk_agg = nullptr, *blk_bnd = nullptr, *blk_chk = nullptr, *blk_fac = nullptr;
     int blk_J = 0;
     hipEvent_t blk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    // block-parallel tail of long-horizon solves: NMPC_BLOCK_TAIL = 0 off | 1 on | unset: on from N = 256 up;
+    // NMPC_BLOCK_J = blocks (unset: ~0.85 sqrt(N), where the two block sweeps and the boundary scan cost the same)
+    int block_tail = -1, block_J = 0;
+    int tail_J = 0, tail_M = 0;      // blocks that hold stages, stages per block (0: the tail is not used by this handle)
+    double *d_ts = nullptr, *d_binfo = nullptr, *tail_agg = nullptr, *tail_bnd = nullptr;
+    int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
@@ -346,6 +352,8 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
+    if (const char *e = std::getenv("NMPC_BLOCK_TAIL")) s->block_tail = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_BLOCK_J")) s->block_J = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -355,6 +363,38 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         g_create_error = s->err;
         nmpc_destroy(s);
         return nullptr;
+    }
+    {
+        // block-parallel tail: the common continuation of a long-horizon work-list instance (one warm interior-point iteration, one
+        // more attempt) with every factorisation cut into blocks.  Needs the FP64 tile kernels, the warm start, and an attempt
+        // schedule in which the second attempt is the last (the tail never leaves a second warm start behind).
+        const nmpc_config &g = s->cfg;
+        const bool can = g.dtype != NMPC_DTYPE_F32 && (g.flags & NMPC_FLAG_TEAM_MAPPING) && !(g.flags & NMPC_FLAG_CONDENSED_QP) && g.qp_polish &&
+                         g.qp_warm_start && g.qp_polish_budget > g.qp_polish_passes && g.qp_polish_budget <= 2 * g.qp_polish_passes &&
+                         g.sim_num_steps <= AS_MAX_STEPS && s->team_qp && s->team_split && s->team_mfma && g.N >= 8;
+        const bool want = s->block_tail < 0 ? g.N >= 256 : s->block_tail != 0;
+        if (can && want) {
+            int J = s->block_J > 0 ? s->block_J : (int)std::lround(0.85 * std::sqrt((double)g.N));
+            J = std::max(2, std::min(J, g.N / 2));
+            const int M = (g.N + J - 1) / J;
+            J = (g.N + M - 1) / M;
+            const size_t Bw = (size_t)s->Bp + 1;
+            bool ok = hipMalloc((void **)&s->d_ts, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->d_binfo, Bw * J * 2 * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->tail_agg, Bw * J * 3 * BLK_MAT * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess;
+            ok = ok && hipMemset(s->d_wl2, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                 hipMemset(s->d_ts, 0, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
+                 hipMemset(s->d_binfo, 0, Bw * J * 2 * sizeof(double)) == hipSuccess;
+            if (!ok) {
+                g_create_error = "hipMalloc of the block-parallel tail's buffers failed";
+                nmpc_destroy(s);
+                return nullptr;
+            }
+            s->tail_J = J; s->tail_M = M;
+            s->ws_bytes += (Bw * TS_ROWS + Bw * J * 2 + Bw * J * 3 * BLK_MAT + Bw * (J + 1) * BLK_MAT) * sizeof(double);
+        }
     }
 #ifdef NMPC_PROFILE
     if (hipMalloc((void **)&s->d_prof, (size_t)8 * s->Bp * sizeof(long long)) != hipSuccess) s->d_prof = nullptr;
@@ -379,7 +419,8 @@ void nmpc_destroy(nmpc_solver *s)
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
-    for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac})
+    for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac, (void *)s->d_ts, (void *)s->d_binfo,
+                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2})
         if (p) (void)hipFree(p);
     for (auto &e : s->blk_ev)
         if (e) (void)hipEventDestroy(e);
@@ -456,7 +497,47 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     if (s->cfg.sim_num_steps <= 2 && !s->as_noflag) HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-    if (s->team_qp) {
+    if (s->team_qp && s->tail_J > 0) {
+        // long horizon: the work list continues in steps - the factorisation of a step by the block-parallel launches of
+        // nmpc_block.hip (J blocks of the horizon at the same time), the rest of the iteration / pass by k_team_tail - and
+        // what leaves the common path is solved by k_team_qp_list from the hand-over, exactly as without the tail
+        WorkList wl2;
+        wl2.count = s->d_wl2; wl2.done = s->d_wl2 + 1; wl2.list = s->d_wl2 + 2;
+        const int ngrid = std::min((B + 3) / 4, 256);
+        AsLaunch tl = al;
+        tl.kind = 3; tl.nlist = ngrid; tl.tpw = 4; tl.occ = 1; tl.lstg = 0;
+        tl.lm_off = as_lds_base(s, c.shared != 0);
+        tl.lds_stride = tl.lm_off + (24 - tl.lm_off % 32 + 32) % 32;
+        tl.lds_bytes = (size_t)4 * tl.lds_stride * sizeof(double);
+        tl.tail.ts = s->d_ts; tl.tail.binfo = s->d_binfo; tl.tail.J = s->tail_J; tl.tail.fb_count = wl2.count; tl.tail.fb_list = wl2.list;
+        BlockLaunch bl;
+        bl.cp = al.cp;
+        bl.g.tAB = (const double *)s->tAB; bl.g.tIV = (const double *)s->iv;
+        bl.g.agg = s->tail_agg; bl.g.bnd = s->tail_bnd; bl.g.bchk = nullptr; bl.g.fac = nullptr;
+        bl.g.Bp = s->Bp; bl.g.B = B; bl.g.J = s->tail_J; bl.g.M = s->tail_M;
+        bl.g.list = wl.list; bl.g.count = wl.count; bl.g.ts = s->d_ts; bl.g.tLM = (double *)s->LM; bl.g.binfo = s->d_binfo;
+        bl.g.shared = c.shared != 0;
+        bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
+        for (auto &e : bl.ev) e = nullptr;
+        HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
+        tl.tail.phase = 0;
+        HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+        tl.tail.phase = 1;
+        HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+        tl.tail.phase = 2;
+        for (int p = 0; p < s->cfg.qp_polish_budget - s->cfg.qp_polish_passes; p++) {
+            HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+            HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+        }
+        AsLaunch ql = al;
+        qp_lds(s, c.shared != 0, ql);
+        ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1; ql.wl = wl2;
+        HIP_TRY(s, (hipError_t)launch_team_qp(ql, in, out));
+        AsLaunch rl = al;
+        rl.kind = 4;
+        HIP_TRY(s, (hipError_t)launch_team_qp(rl, in, out));
+    } else if (s->team_qp) {
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1;
@@ -1060,6 +1141,22 @@ int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out)
     HIP_TRY(s, hipMemcpy2D(host_out, BLK_FAC_ROWS * sizeof(double), (const double *)s->LM + TLM_MT, TLM_ROWS * sizeof(double),
                            BLK_FAC_ROWS * sizeof(double), (size_t)B * s->cfg.N, hipMemcpyDeviceToHost));
     return 0;
+}
+
+// diagnostic: where the block-parallel tail left the instances of the last solve - per instance 0 not in the work list (or no tail),
+// 3 finished by the tail, 5 handed to the fallback list; returns the number of blocks the tail uses (0: this handle has no tail)
+int nmpc_debug_tail_states(nmpc_solver *s, int B, int32_t *host_out)
+{
+    if (!s) return NMPC_EARG;
+    if (B < 1 || B > s->Bp || !host_out) return s->fail(NMPC_EARG, "debug_tail_states: bad arguments");
+    for (int i = 0; i < B; i++) host_out[i] = 0;
+    if (s->tail_J == 0) return 0;
+    HIP_TRY(s, hipSetDevice(s->cfg.device));
+    HIP_TRY(s, hipDeviceSynchronize());
+    std::vector<double> ts((size_t)B * TS_ROWS);
+    HIP_TRY(s, hipMemcpy(ts.data(), s->d_ts, ts.size() * sizeof(double), hipMemcpyDeviceToHost));
+    for (int i = 0; i < B; i++) host_out[i] = (int32_t)ts[(size_t)i * TS_ROWS];
+    return s->tail_J;
 }
 
 int nmpc_plant_step_device(nmpc_solver *s, int B, const void *x, const void *u, void *x_next, int normalize_q,

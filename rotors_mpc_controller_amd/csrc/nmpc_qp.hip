@@ -60,9 +60,44 @@ __global__ __launch_bounds__(64, 1) void k_team_qp_list(const Consts<double> *__
     }
 }
 
+// One step of the block-parallel tail of a long-horizon solve (team_as MODE 3): the work-list instances whose tail state asks for
+// this phase; the factorisation of the step was done by the launches of nmpc_block.hip.  The list is NOT reset here.
+template <bool SHARED, bool TRAJ, class TI>
+__global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
+                                                     TeamWork<double> tw, WorkList wl, int B, int lds_stride, int lm_off, TailCtx tcx)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = *wl.count;
+    const int team = (threadIdx.x >> 2) & 3;
+    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
+        const int e = base + team;
+        const int inst = e < n ? wl.list[e] : -1;
+        const int st = inst >= 0 ? (int)tcx.ts[(size_t)inst * TS_ROWS] : (int)TS_NONE;
+        const bool act = inst >= 0 && (tcx.phase == 0 || (tcx.phase == 1 && st == TS_IPM) || (tcx.phase == 2 && st == TS_AS));
+        if (__ballot(act) == 0) continue;
+        team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
+                                           act ? inst : -1, tcx);
+        __syncthreads();
+    }
+}
+
+__global__ void k_list_reset(WorkList wl) { *wl.count = 0; *wl.done = 0; }
+
 template <class TI>
 int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 {
+    if (a.kind == 4) {
+        hipLaunchKernelGGL(k_list_reset, dim3(1), dim3(1), 0, a.stream, a.wl);
+        return (int)hipGetLastError();
+    }
+    if (a.kind == 3) {
+        const dim3 grid(a.nlist), block(64);
+#define NMPC_LAUNCH_TL(SH_, TR_) hipLaunchKernelGGL((k_team_tail<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.lds_stride, a.lm_off, a.tail)
+        if (a.shared) { if (a.traj) NMPC_LAUNCH_TL(true, true); else NMPC_LAUNCH_TL(true, false); }
+        else { if (a.traj) NMPC_LAUNCH_TL(false, true); else NMPC_LAUNCH_TL(false, false); }
+#undef NMPC_LAUNCH_TL
+        return (int)hipGetLastError();
+    }
     if (a.kind == 1) {
         const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
 #define NMPC_LAUNCH_QP(SH_, TR_) hipLaunchKernelGGL((k_team_qp<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off)

@@ -41,6 +41,7 @@ constexpr int TLM_ROWS = 240;      // M (52) | L (10) | m (4) | xhat of the poli
                                    // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16) |
                                    // stages with pins: (B'Pbar Abar)^T unmasked (64) | (B'PB)^T (16)
 constexpr int TLM_MT = 80, TLM_Z = 144, TLM_G = 160;
+constexpr int TLM_RINV = 52;       // tile form with H_uu = L D L': the four 1 / d_a of a stage (52..63: the slot of the row form's L | m, unused there)
 // TAB_ROWS (nmpc_lane.hpp): 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad here; 12 tiles x 16 in the active-set kernel
 constexpr int TP_ROW = 14;          // one row of the Riccati matrix P_k (13) and p_k, per stage checkpoint
 constexpr int TP_ROWS = 256;        // per stage: 13 x 14 (VALU form) or 16 tiles x 16 lanes (MFMA form)
@@ -66,6 +67,13 @@ constexpr int L_Z = L_RED + 32;     // [32] the 28 entries of the (q,omega)x(q,o
 // (A stride of 800 doubles = 25 bank rows made every broadcast read a 4-way conflict:
 // SQ_LDS_BANK_CONFLICT was 20 % of the wave cycles; 848 = 128 B past a row is 2-way with this lane map.)
 constexpr int TEAM_LDS = L_Z + 48;
+
+// Tail state of a long-horizon work-list instance between the launches of the block-parallel tail: one row of
+// TS_ROWS doubles per instance
+constexpr int TS_ROWS = 16;
+enum { TS_NONE = 0, TS_IPM = 1, TS_AS = 2, TS_DONE = 3, TS_FALLBACK = 4, TS_LISTED = 5 };
+// [0] state  [1] passes spent  [2] passes of the attempt in flight  [3] growth reference  [4] mu  [5] rho  [6] interior-point iterations
+// [7] threshold of the next attempt  [8] last step  [9] the iterate descends from a warm start
 
 template <class T>
 struct TeamWork {

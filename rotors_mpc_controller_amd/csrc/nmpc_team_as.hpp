@@ -48,7 +48,6 @@ template <int MS> struct EvLayout {
 };
 constexpr int AS_LM_ROWS = 80;       // doubles per stage in the LDS stage cache: Mbar^T tiles (64) | L^-1 tile (16)
 constexpr int IP_LM_ROWS = 88;       // ... of the kernels that also iterate the interior point method: | 1 / d_a of H_uu = L D L' (4) | pad
-constexpr int TLM_RINV = 52;         // the same four reciprocals in a stage's HBM row (52..63: the slot of the row form's L | m, unused here)
 // LDS carve per team, in doubles
 constexpr int A_AD = 0;              // [16][8]  rows of the dense A columns (natural layout)
 constexpr int A_B = A_AD + 128;      // [16][4]
@@ -93,14 +92,27 @@ struct WorkList {
     int *list;      // [Bp] instance indices
 };
 
+// context of one step of the block-parallel tail (MODE 3)
+struct TailCtx {
+    double *ts = nullptr;            // [Bp + 1][TS_ROWS] tail state (nmpc_team.hpp)
+    const double *binfo = nullptr;   // [Bp + 1][J][2] verdict of the block factorisation of this step (nmpc_block.hpp)
+    int J = 0;
+    int phase = 0;                   // 0: install the warm start | 1: the rest of an interior-point iteration | 2: the rest of an active-set pass
+    int *fb_count = nullptr;         // fallback list: what the tail does not finish (solved by k_team_qp_list from the hand-over)
+    int *fb_list = nullptr;
+};
+
 // MODE 0: preparation + the FIRST active-set attempt, give-ups to the work list (k_team_as: the first launch of the default path)
 // MODE 1: the whole QP for every instance of the batch - interior-point iterations, with the active-set attempts in between
 //         when qp_polish is on (k_team_qp: qp_polish = 0, an attempt schedule that does not start with an attempt, NMPC_TEAM_SPLIT=0)
 // MODE 2: the same for ONE chunk of the work list, continuing after a failed first attempt (k_team_qp_list: the second launch)
+// MODE 3: ONE step of a work-list instance whose factorisation came from the block-parallel launches of nmpc_block.hpp (k_team_tail:
+//         long horizons) - no factor sweep in here
 template <bool SHARED, bool TRAJ, bool LDSC, class TI, int MODE = 0>
 __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
                                         const Outputs<TI> &out, const TeamWork<double> &tw, const WorkList &wl,
-                                        int B, int tpw, double *smem, int lds_stride, int lstg, int lm_off, int inst_ov = -2)
+                                        int B, int tpw, double *smem, int lds_stride, int lstg, int lm_off, int inst_ov = -2,
+                                        const TailCtx tcx = TailCtx())
 {
     // lds_stride: doubles of LDS per team (carve below + the stage cache at lm_off: [lstg][LMR]); lstg: the factors of stages 0 .. lstg-1 -
     // written last by the backward sweep and read first by the forward sweep - stay in LDS and never reach HBM
@@ -119,8 +131,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     const int ta = r >> 2, tc = r & 3, j = tc;
     const int rr = r < NX ? r : NX - 1;
     const bool rowl = r < NX, cmpl = r < NU;
-    int inst = MODE == 2 ? inst_ov : blockIdx.x * tpw + team;
-    const bool valid = MODE == 2 ? (inst >= 0 && inst < B) : (team < tpw && inst < B);
+    int inst = MODE >= 2 ? inst_ov : blockIdx.x * tpw + team;
+    const bool valid = MODE >= 2 ? (inst >= 0 && inst < B) : (team < tpw && inst < B);
     if (!valid) inst = B - 1;             // idle teams read the inputs of the last instance ...
     const int winst = valid ? inst : w.Bp;   // ... and work in a spare workspace row, so that no store of a sweep is predicated
     const int lane = inst;                // profiling slot (NMPC_PROFILE builds)
@@ -273,6 +285,17 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                                     S[A_B + natR[rt] * NU + tc] = Sx[q][rt][2];
                                 }
                             }
+                            if (MODE == 3) {
+                                // the block-parallel factorisation reads the stage as tiles from the HBM scratch: stage 0 of the instance's rows
+                                T *a = w.tAB + (size_t)winst * N * TAB_ROWS + r;
+                                NMPC_UNROLL for (int rt = 0; rt < 4; rt++) {
+                                    const T bq = sbv[natR[rt] >= 0 ? natR[rt] : 0];
+                                    const T c15 = natR[rt] >= 0 ? bq : ((rt == 3 && ta == 3) ? T(1) : T(0));
+                                    if (rt < 3) a[(rt * 3 + 0) * 16] = Sx[q][rt][0];
+                                    a[(rt * 3 + 1) * 16] = tc < 3 ? Sx[q][rt][1] : c15;
+                                    a[(rt * 3 + 2) * 16] = Sx[q][rt][2];
+                                }
+                            }
                         } else {
                             // per-stage linearisation: the 12 tiles of [Aq | Aw b | B] of the padded homogeneous form go to
                             // the HBM scratch as tiles - tile (rt,ct) at [(3 rt + ct) 16 + r]: the factor sweep reads its
@@ -295,7 +318,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             NMPC_STAMP(4)
         }
     };
-    if (c.steps <= 2) prepare(std::integral_constant<int, 2>{}); else prepare(std::integral_constant<int, AS_MAX_STEPS>{});
+    if (SHARED || MODE != 3) {       // (MODE 3, per-stage variant: the tiles the first launch left in the HBM scratch are current)
+        if (c.steps <= 2) prepare(std::integral_constant<int, 2>{}); else prepare(std::integral_constant<int, AS_MAX_STEPS>{});
+    }
     __syncthreads();          // stage matrices (LDS, or this wave's own global rows) visible to every lane
     NMPC_STAMP(7)
 
@@ -1182,6 +1207,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         roll_bad = bad;
     };
 
+    // verdict of an external factorisation (MODE 3): usable | NaN pivot | team-wide max |B'PB|
+    bool ext_ok = true, ext_nan = false;
+    T ext_gm = 0;
     // ================= one active-set pass of every team of the wave that is in an attempt (mode M_POL)
     auto as_pass = [&]() {
         pol = mode == M_POL;
@@ -1206,14 +1234,19 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
 
         ok = true; nanp = false; gm = 0;
-        if (nopins_pass) sweepA(NoPins{}, NoIpm{}); else sweepA(WithPins{}, NoIpm{});
-        NMPC_STAMP(0)
-        __syncthreads();
-        // growth certificate: the team-wide max |B'PB| of this sweep against that of the first factorisation of the solve
-        sh[r] = gm;
-        NMPC_WSYNC();
-        T gt = sh[0];
-        NMPC_UNROLL for (int i = 1; i < 16; i++) gt = fmax(gt, sh[i]);
+        T gt;
+        if constexpr (MODE == 3) {
+            ok = ext_ok; nanp = ext_nan; gt = ext_gm;    // the factorisation came from the block-parallel launches
+        } else {
+            if (nopins_pass) sweepA(NoPins{}, NoIpm{}); else sweepA(WithPins{}, NoIpm{});
+            NMPC_STAMP(0)
+            __syncthreads();
+            // growth certificate: the team-wide max |B'PB| of this sweep against that of the first factorisation of the solve
+            sh[r] = gm;
+            NMPC_WSYNC();
+            gt = sh[0];
+            NMPC_UNROLL for (int i = 1; i < 16; i++) gt = fmax(gt, sh[i]);
+        }
         if (pol && gbase == T(0)) gbase = gt;
         const bool trip = pol && c.growth_max > T(0) && gt > c.growth_max * gbase;
         bool pol_fail = false;
@@ -1262,11 +1295,115 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     };
 
     int it = 0;              // interior-point iterations taken
+    bool tail_fin = false;   // MODE 3: this step ended the instance on an accepted pass
     if constexpr (MODE == 0) {
         for (;;) {
             if (__ballot(mode == M_POL) == 0) break;
             nopins_pass = pass == 0;
             as_pass();
+        }
+    } else if constexpr (MODE == 3) {
+        // ---- one step of the block-parallel tail.  The factorisation of this step was done by the launches
+        // of nmpc_block.hpp; what remains of an interior-point iteration (phase 1) or of an active-set pass (phase 2) runs here, and
+        // the team's state travels in its tail-state row.  The tail covers the common continuation of a long-horizon instance - one
+        // interior-point iteration from the warm start, then one more attempt - with the same sweeps as MODE 2; anything else (no warm
+        // start, a factorisation that cannot be used, a second iteration, an attempt that fails) goes to the fallback list, which
+        // k_team_qp_list solves from the active-set kernel's hand-over as if the tail had not run.
+        const T nc = T(2 * NU) * T(N);
+        T *tsr = tcx.ts + (size_t)winst * TS_ROWS;
+        int tstate = valid ? (int)tsr[0] : (int)TS_NONE;
+        T mu = tsr[4], rho = tsr[5], pol_mu = tsr[7], step_last = tsr[8];
+        npol = (int)tsr[1]; pass_in_attempt = (int)tsr[2]; gbase = tsr[3]; it = (int)tsr[6];
+        if (tcx.phase != 0) {
+            const T *bi = tcx.binfo + (size_t)winst * tcx.J * 2;
+            for (int b = 0; b < tcx.J; b++) {
+                const T fl = bi[2 * b + 1];
+                ext_gm = fmax(ext_gm, bi[2 * b]); ext_ok &= fl == T(0); ext_nan |= fl == T(2);
+            }
+        }
+        mode = M_DONE;
+        if (tcx.phase == 0) {
+            const int np0 = w.npol[inst];
+            npol = np0 < 0 ? -np0 : np0; pass_in_attempt = 0;
+            pol_mu = c.polish_mu * T(1e-2);
+            const T gb0 = w.gbase[inst];
+            gbase = fabs(gb0);
+            warm_avail = valid && gb0 < T(0);
+            mu = c.mu0; rho = T(1); step_last = 0;
+            if (__ballot(warm_avail) != 0) {
+                tIV = warm_avail ? tIV_own : tIV_spare;
+                sweepW(Ipm{});
+                sh[r] = msF;
+                __syncthreads();
+                T ms = 0;
+                NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
+                mu = ms / nc;
+                __syncthreads();
+            }
+            tstate = valid ? (warm_avail ? (int)TS_IPM : (int)TS_FALLBACK) : (int)TS_NONE;
+            warm_avail = false;
+            it = 1;               // the iteration the next launches perform
+        } else if (tcx.phase == 1) {
+            const bool ipm = tstate == TS_IPM;
+            if (__ballot(ipm) != 0) {
+                const bool trip = c.growth_max > T(0) && !(ext_gm <= c.growth_max * gbase);
+                const bool ipm2 = ipm && ext_ok && !trip;
+                pol = false; pol2 = false;
+                tLM = ipm2 ? tLM_own : tLM_spare; tIV = ipm2 ? tIV_own : tIV_spare; tP = tP_spare;
+                viol = false; heavy = false; kchgB = -1; xh = 0;
+                sweepB(NoPins{}, Ipm{}, NoWarm{});
+                __syncthreads();
+                {
+                    const T rmax = fmax(fmax(sRed[4], sRed[5]), fmax(sRed[6], sRed[7]));
+                    const T s2 = sRed[8] + sRed[9] + sRed[10] + sRed[11];
+                    const T aaff = T(1) / rmax;
+                    const T muaff = (T(1) - aaff) * mu + aaff * aaff * s2 / nc;
+                    T sg3 = muaff / mu;
+                    sg3 = sg3 * sg3 * sg3;
+                    sigmu = sg3 * mu;
+                }
+                sweepD(Ipm{});
+                __syncthreads();
+                sweepE(Ipm{});
+                if (tc == 0) { sRed[12 + ta] = rmaxE; sRed[20 + ta] = dmaxE; }
+                __syncthreads();
+                const T rmx = fmax(fmax(sRed[12], sRed[13]), fmax(sRed[14], sRed[15]));
+                const T dmx = fmax(fmax(sRed[20], sRed[21]), fmax(sRed[22], sRed[23]));
+                const T alpha = c.tau / rmx;
+                sweepF(alpha);
+                sh[r] = msF;
+                __syncthreads();
+                T ms = 0;
+                NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
+                const bool good = ipm2 && alpha == alpha && !(alpha < T(1e-12));
+                if (good) { rho *= (T(1) - alpha); mu = ms / nc; step_last = alpha * dmx; }
+                // what the interior point does next (top of its loop in the other modes): the tail follows it into an attempt only
+                const bool conv = mu <= c.tol_comp && rho <= c.tol_stat && (!(c.tol_step > T(0)) || step_last <= c.tol_step);
+                const bool attempt = c.polish && mu <= pol_mu && npol < c.polish_budget;
+                if (ipm) tstate = (good && mu == mu && !conv && attempt) ? (int)TS_AS : (int)TS_FALLBACK;
+                pass_in_attempt = 0;
+                __syncthreads();
+            }
+        } else {
+            mode = tstate == TS_AS ? M_POL : M_DONE;
+            if (__ballot(mode == M_POL) != 0) {
+                nopins_pass = false;
+                k_top = N - 1; ck_valid = 0;
+                as_pass();
+                if (tstate == TS_AS) tstate = mode == M_DONE ? (int)TS_DONE : (mode == M_POL ? (int)TS_AS : (int)TS_FALLBACK);
+                tail_fin = tstate == TS_DONE && status == 0;
+                if (tstate == TS_DONE && status != 0) tstate = TS_FALLBACK;
+            }
+            mode = M_DONE;
+        }
+        if (valid && r == 0) {
+            if (tstate == TS_FALLBACK) {
+                const int slot = atomicAdd(tcx.fb_count, 1);
+                tcx.fb_list[slot] = inst;
+                tstate = TS_LISTED;
+            }
+            tsr[0] = (T)tstate; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase; tsr[4] = mu; tsr[5] = rho;
+            tsr[6] = (T)it; tsr[7] = pol_mu; tsr[8] = step_last;
         }
     } else {
         // ---- phases of a wave: interior-point iterations for the teams in that mode until each has converged, failed or
@@ -1421,7 +1558,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     if constexpr (MODE != 0) {
         // QP status -> acados numbering (oracle orc_sqp_rti): iteration cap tolerated or reported (U10 switch), min step -> QP failure
         nlp_status = status == 2 ? (c.maxiter_status ? 2 : 0) : (status == 3 ? 4 : status);
-        const bool need_roll = valid && !from_ua && nlp_status == 0;
+        const bool need_roll = MODE != 3 && valid && !from_ua && nlp_status == 0;
         if (__ballot(need_roll) != 0) {
             tLM = need_roll ? tLM_own : tLM_spare; tIV = need_roll ? tIV_own : tIV_spare;
             rollout(Ipm{});
@@ -1433,6 +1570,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     NMPC_PROF_END(w)
     tLM = tLM_own; tIV = tIV_own;
     if (!valid) return;
+    if (MODE == 3 && !tail_fin) return;          // the instance is still in the tail, or went to the fallback list
     if (MODE == 0 && mode == M_GIVEUP) {
         if (r == 0) {
             // the work-list launch resumes the pass budget from here (all of it spent when the growth certificate ended the

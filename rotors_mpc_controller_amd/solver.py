@@ -186,6 +186,15 @@ class NmpcOcpSolver:
         self._check(self._lib.nmpc_debug_factors(self._h, int(B), out.ctypes.data_as(C.POINTER(C.c_double))))
         return out
 
+    def tail_states(self, B: int):
+        """(blocks, states [B]) of the block-parallel tail after the last solve: 0 not in the work list, 3 finished by the tail,
+        5 handed on to the sequential work-list kernel; blocks = 0 when this handle runs no tail."""
+        out = np.zeros(int(B), dtype=np.int32)
+        rc = self._lib.nmpc_debug_tail_states(self._h, int(B), out.ctypes.data_as(C.POINTER(C.c_int32)))
+        if rc < 0:
+            self._check(rc)
+        return rc, out
+
     def device_iterations_ptr(self) -> int:
         return int(self._lib.nmpc_device_iterations(self._h) or 0)
 

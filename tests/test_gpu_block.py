@@ -88,3 +88,76 @@ def test_block_factor_rejects_what_it_cannot_do():
     with pytest.raises(RuntimeError, match="blocks"):
         s.block_factor_device(8, 0, x0.data_ptr(), yr.data_ptr(), ye_d.data_ptr(), True)
     s.close()
+
+
+WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
+
+
+def _solve_both(monkeypatch, over, x0, yref, ye, J, warm_from=None):
+    """the same solve with the work list continued sequentially (k_team_qp_list) and by the block-parallel tail"""
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    res = []
+    for tail in ("0", "1"):
+        monkeypatch.setenv("NMPC_BLOCK_TAIL", tail)
+        if J:
+            monkeypatch.setenv("NMPC_BLOCK_J", str(J))
+        s = NmpcOcpSolver(_lib.default_config(**over))
+        kw = dict(x_init=warm_from["x"], u_init=warm_from["u"]) if warm_from else {}
+        out = s.solve_batch(x0, yref, ye, want_traj=True, **kw)
+        it, ps = s.counts()
+        st = s.stats()
+        st["tail_blocks"], st["tail_states"] = s.tail_states(len(x0))
+        res.append((out, it.copy(), ps.copy(), st))
+        s.close()
+    return res
+
+
+@pytest.mark.parametrize("N,B,dist,J,over", [
+    (600, 1024, NEAR_HOVER, 0, {}),                                          # config 5: ~100 instances in the tail
+    (600, 256, NEAR_HOVER, 12, {}),
+    (57, 512, WILD, 6, {}),                                                  # short horizon, tail forced on: most of the batch passes through it
+    (20, 512, WILD, 4, dict(qp_polish_passes=3, qp_polish_budget=6)),        # tight attempts: many instances leave the tail for the fallback list
+])
+def test_block_parallel_tail_gives_the_results_of_the_sequential_work_list(N, B, dist, J, over, monkeypatch):
+    """The long-horizon tail (one warm interior-point iteration, one more attempt, every factorisation cut into blocks - DESIGN 4.6)
+    against the sequential continuation of the same work list, cold (one shared linearisation) and warm-started (per stage):
+    statuses, interior-point iterations and pass counts equal on every instance; commands and trajectories to 1e-9 / 1e-8."""
+    over = dict(over, N=N, max_batch=B)
+    yref, ye = hover_reference(N, 0.68 * 9.81 / 4.0)
+    x0 = sample_x0(B, 5, **dist)
+    (a, ita, psa, sta), (b, itb, psb, stb) = _solve_both(monkeypatch, over, x0, yref, ye, J)
+    assert sta["n_tail"] > 0 and sta["n_tail"] == stb["n_tail"]
+    assert sta["tail_blocks"] == 0 and stb["tail_blocks"] == (J or round(0.85 * N ** 0.5))
+    fin, fb = int((stb["tail_states"] == 3).sum()), int((stb["tail_states"] == 5).sum())
+    assert fin + fb == stb["n_tail"] and fin > 0                 # every work-list instance went through the tail, some to the end
+    if over.get("qp_polish_passes"):
+        assert fb > 0                                            # ... and with tight attempts some to the fallback list
+    np.testing.assert_array_equal(a["status"], b["status"])
+    np.testing.assert_array_equal(ita, itb)
+    np.testing.assert_array_equal(psa, psb)
+    ok = a["status"] == 0
+    np.testing.assert_allclose(b["u0"][ok], a["u0"][ok], rtol=0, atol=1e-9)
+    np.testing.assert_allclose(b["x"][ok], a["x"][ok], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(b["u"][ok], a["u"][ok], rtol=0, atol=1e-8)
+    # second solve from the first one's trajectories: the per-stage linearisation through the same two paths
+    if N <= 100:
+        (a2, ita2, psa2, sta2), (b2, itb2, psb2, stb2) = _solve_both(monkeypatch, over, x0, yref, ye, J, warm_from=a)
+        np.testing.assert_array_equal(a2["status"], b2["status"])
+        np.testing.assert_array_equal(ita2, itb2)
+        np.testing.assert_array_equal(psa2, psb2)
+        ok2 = a2["status"] == 0
+        np.testing.assert_allclose(b2["u0"][ok2], a2["u0"][ok2], rtol=0, atol=1e-9)
+
+
+def test_block_parallel_tail_on_a_per_stage_linearisation_at_the_long_horizon(monkeypatch):
+    """N = 600 without the shared cold-start linearisation (what a warm-started tick runs): tail against sequential work list."""
+    N, B = 600, 256
+    over = dict(N=N, max_batch=B, flags=_lib.FLAG_TEAM_MAPPING)
+    yref, ye = hover_reference(N, 0.68 * 9.81 / 4.0)
+    x0 = sample_x0(B, 5, **NEAR_HOVER)
+    (a, ita, psa, sta), (b, itb, psb, stb) = _solve_both(monkeypatch, over, x0, yref, ye, 0)
+    assert sta["n_tail"] >= 8
+    np.testing.assert_array_equal(a["status"], b["status"])
+    np.testing.assert_array_equal(ita, itb)
+    np.testing.assert_array_equal(psa, psb)
+    np.testing.assert_allclose(b["u0"], a["u0"], rtol=0, atol=1e-9)
