@@ -61,6 +61,7 @@ __global__ __launch_bounds__(64, 1) void k_block_scan_tail(BlockWork g)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
     const int n = *g.count;
+    if (blockIdx.x == 0 && threadIdx.x == 0 && g.reset_count) *g.reset_count = 0;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         int inst;
         const bool act = tail_pick(g, base, n, inst);

@@ -50,8 +50,9 @@ struct BlockWork {
     int Bp, B, J, M;       // M = stages per block
     // tail mode (the long-horizon work list): instances come from the work list, what is factorised is decided
     // by the instance's tail state, factors go straight into the solver's own rows
-    const int *list;       // work list of the active-set kernel, *count entries
+    const int *list;       // (compacted) work list of this step, *count entries
     const int *count;
+    int *reset_count;      // count of the list the NEXT step's instances are appended to: zeroed by the scan of this step (nobody reads it now)
     const double *ts;      // [Bp + 1][TS_ROWS] tail state (nmpc_team.hpp)
     double *tLM;           // [Bp + 1][N][TLM_ROWS]
     double *binfo;         // [Bp + 1][J][2] per block: max |B'PB| of the final sweep | 0 ok, 1 pivot not positive, 2 NaN pivot

@@ -149,11 +149,12 @@ struct nmpc_solver {
     int blk_J = 0;
     hipEvent_t blk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
     // block-parallel tail of long-horizon solves: NMPC_BLOCK_TAIL = 0 off | 1 on | unset: on from N = 256 up;
-    // NMPC_BLOCK_J = blocks (unset: ~0.85 sqrt(N), where the two block sweeps and the boundary scan cost the same)
-    int block_tail = -1, block_J = 0;
+    // NMPC_BLOCK_J = blocks (unset: ~0.7 sqrt(N): measured optimum of config 5, 10.0 ms at J = 16-17 against 10.3 at 21 and 10.6 at 10)
+    int block_tail = -1, block_J = 0, tail_cap = 1;   // NMPC_TAIL_CAP: passes of the first attempt the first launch performs itself
     int tail_J = 0, tail_M = 0;      // blocks that hold stages, stages per block (0: the tail is not used by this handle)
     double *d_ts = nullptr, *d_binfo = nullptr, *tail_agg = nullptr, *tail_bnd = nullptr;
     int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
+    int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
@@ -354,6 +355,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
     if (const char *e = std::getenv("NMPC_BLOCK_TAIL")) s->block_tail = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_BLOCK_J")) s->block_J = std::atoi(e);
+    if (const char *e = std::getenv("NMPC_TAIL_CAP")) s->tail_cap = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -374,7 +376,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
                          g.sim_num_steps <= AS_MAX_STEPS && s->team_qp && s->team_split && s->team_mfma && g.N >= 8;
         const bool want = s->block_tail < 0 ? g.N >= 256 : s->block_tail != 0;
         if (can && want) {
-            int J = s->block_J > 0 ? s->block_J : (int)std::lround(0.85 * std::sqrt((double)g.N));
+            int J = s->block_J > 0 ? s->block_J : (int)std::lround(0.7 * std::sqrt((double)g.N));
             J = std::max(2, std::min(J, g.N / 2));
             const int M = (g.N + J - 1) / J;
             J = (g.N + M - 1) / M;
@@ -383,8 +385,10 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
                       hipMalloc((void **)&s->d_binfo, Bw * J * 2 * sizeof(double)) == hipSuccess &&
                       hipMalloc((void **)&s->tail_agg, Bw * J * 3 * BLK_MAT * sizeof(double)) == hipSuccess &&
                       hipMalloc((void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess;
+                      hipMalloc((void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                      hipMalloc((void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess;
             ok = ok && hipMemset(s->d_wl2, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                 hipMemset(s->d_wl3, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_ts, 0, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
                  hipMemset(s->d_binfo, 0, Bw * J * 2 * sizeof(double)) == hipSuccess;
             if (!ok) {
@@ -420,7 +424,7 @@ void nmpc_destroy(nmpc_solver *s)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac, (void *)s->d_ts, (void *)s->d_binfo,
-                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2})
+                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3})
         if (p) (void)hipFree(p);
     for (auto &e : s->blk_ev)
         if (e) (void)hipEventDestroy(e);
@@ -493,11 +497,18 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
     al.lds_stride = lds_stride; al.lstg = lstg; al.lm_off = base_as; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
     al.lds_bytes = lds_as; al.stream = st;
+    const bool tail = s->team_qp && s->tail_J > 0;
+    const int cap = tail ? std::max(1, std::min(s->tail_cap > 0 ? s->tail_cap : s->cfg.qp_polish_passes, s->cfg.qp_polish_passes)) : 0;
+    if (tail) {
+        HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
+        al.tail.cap = cap < s->cfg.qp_polish_passes ? cap : 0;
+        al.tail.ts = s->d_ts;
+    }
     // k_team_as: the flag build (nmpc_as.hip) for what it is validated on, the default-codegen build (nmpc_qp.hip) otherwise
     if (s->cfg.sim_num_steps <= 2 && !s->as_noflag) HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-    if (s->team_qp && s->tail_J > 0) {
+    if (tail) {
         // long horizon: the work list continues in steps - the factorisation of a step by the block-parallel launches of
         // nmpc_block.hip (J blocks of the horizon at the same time), the rest of the iteration / pass by k_team_tail - and
         // what leaves the common path is solved by k_team_qp_list from the hand-over, exactly as without the tail
@@ -519,23 +530,36 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         bl.g.shared = c.shared != 0;
         bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
         for (auto &e : bl.ev) e = nullptr;
-        HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
-        tl.tail.phase = 0;
-        HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
-        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
-        tl.tail.phase = 1;
-        HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
-        tl.tail.phase = 2;
-        for (int p = 0; p < s->cfg.qp_polish_budget - s->cfg.qp_polish_passes; p++) {
-            HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+        // the work list is compacted from step to step: every step reads one list and appends what is still in the tail to the other
+        WorkList lists[2];
+        lists[0] = wl;
+        lists[1].count = s->d_wl3; lists[1].done = s->d_wl3 + 1; lists[1].list = s->d_wl3 + 2;
+        int cur = 0;
+        auto step = [&](int phase, bool factor) -> int {
+            tl.wl = lists[cur]; tl.tail.nx_count = lists[cur ^ 1].count; tl.tail.nx_list = lists[cur ^ 1].list;
+            tl.tail.phase = phase;
+            if (factor) {
+                bl.g.list = lists[cur].list; bl.g.count = lists[cur].count; bl.g.reset_count = nullptr;
+                // the list this step appends to was consumed by the previous step: its count is zeroed between the two block sweeps
+                bl.g.reset_count = lists[cur ^ 1].count;
+                HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+            }
             HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
-        }
+            cur ^= 1;
+            return 0;
+        };
+        if (step(0, false)) return NMPC_EHIP;
+        for (int p = cap; p < s->cfg.qp_polish_passes; p++)          // the rest of the first attempt
+            if (step(2, true)) return NMPC_EHIP;
+        if (step(1, true)) return NMPC_EHIP;                         // one interior-point iteration from the warm start
+        for (int p = 0; p < s->cfg.qp_polish_budget - s->cfg.qp_polish_passes; p++)   // the second attempt
+            if (step(2, true)) return NMPC_EHIP;
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1; ql.wl = wl2;
         HIP_TRY(s, (hipError_t)launch_team_qp(ql, in, out));
         AsLaunch rl = al;
-        rl.kind = 4;
+        rl.kind = 4; rl.tail.nx_count = lists[1].count;
         HIP_TRY(s, (hipError_t)launch_team_qp(rl, in, out));
     } else if (s->team_qp) {
         AsLaunch ql = al;

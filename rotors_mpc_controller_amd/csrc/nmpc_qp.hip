@@ -20,12 +20,16 @@ namespace {
 // per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
 template <bool SHARED, bool TRAJ, int OCC, class TI>
 __global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
-                                                     TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg, int lm_off)
+                                                     TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg, int lm_off,
+                                                     int pass_cap, double *tail_ts)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // the constant block is read from device memory (uploaded at create): scalar loads on demand for uniform entries,
     // one vector load for a per-lane entry
-    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off);
+    // (pass_cap > 0: long horizons - the attempt is handed to the block-parallel tail after that many passes, tail_ts its state rows)
+    TailCtx tcx;
+    tcx.cap = pass_cap; tcx.ts = tail_ts;
+    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, -2, tcx);
 }
 
 // The whole QP of every instance of the batch in one launch (team_as MODE 1): interior-point iterations in the tile form,
@@ -74,6 +78,11 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
         const int inst = e < n ? wl.list[e] : -1;
         const int st = inst >= 0 ? (int)tcx.ts[(size_t)inst * TS_ROWS] : (int)TS_NONE;
         const bool act = inst >= 0 && (tcx.phase == 0 || (tcx.phase == 1 && st == TS_IPM) || (tcx.phase == 2 && st == TS_AS));
+        // an instance that is in the tail but not part of this phase stays on the (compacted) list of the next step
+        if (inst >= 0 && !act && (st == TS_IPM || st == TS_AS) && (threadIdx.x & 0x33) == 0) {
+            const int slot = atomicAdd(tcx.nx_count, 1);
+            tcx.nx_list[slot] = inst;
+        }
         if (__ballot(act) == 0) continue;
         team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
                                            act ? inst : -1, tcx);
@@ -81,13 +90,13 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
     }
 }
 
-__global__ void k_list_reset(WorkList wl) { *wl.count = 0; *wl.done = 0; }
+__global__ void k_list_reset(WorkList wl, int *second_count) { *wl.count = 0; *wl.done = 0; if (second_count) *second_count = 0; }
 
 template <class TI>
 int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 {
     if (a.kind == 4) {
-        hipLaunchKernelGGL(k_list_reset, dim3(1), dim3(1), 0, a.stream, a.wl);
+        hipLaunchKernelGGL(k_list_reset, dim3(1), dim3(1), 0, a.stream, a.wl, a.tail.nx_count);
         return (int)hipGetLastError();
     }
     if (a.kind == 3) {
@@ -115,7 +124,7 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
         return (int)hipGetLastError();
     }
     const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
-#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off)
+#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off, a.tail.cap, a.tail.ts)
     if (a.shared) {
         if (a.occ == 2) { if (a.traj) NMPC_LAUNCH_AS(true, true, 2); else NMPC_LAUNCH_AS(true, false, 2); }
         else { if (a.traj) NMPC_LAUNCH_AS(true, true, 1); else NMPC_LAUNCH_AS(true, false, 1); }

@@ -100,6 +100,9 @@ struct TailCtx {
     int phase = 0;                   // 0: install the warm start | 1: the rest of an interior-point iteration | 2: the rest of an active-set pass
     int *fb_count = nullptr;         // fallback list: what the tail does not finish (solved by k_team_qp_list from the hand-over)
     int *fb_list = nullptr;
+    int cap = 0;                     // MODE 0: passes the first launch performs before it hands a running attempt to the tail (0: all)
+    int *nx_count = nullptr;         // the work list of the NEXT step: instances that are still in the tail after this one (the list is
+    int *nx_list = nullptr;          // compacted from step to step: a wave costs the same with one live team as with four)
 };
 
 // MODE 0: preparation + the FIRST active-set attempt, give-ups to the work list (k_team_as: the first launch of the default path)
@@ -1299,6 +1302,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     if constexpr (MODE == 0) {
         for (;;) {
             if (__ballot(mode == M_POL) == 0) break;
+            if (tcx.cap > 0 && pass >= tcx.cap) break;       // long horizon: the block-parallel tail continues the attempt
             nopins_pass = pass == 0;
             as_pass();
         }
@@ -1323,12 +1327,12 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         }
         mode = M_DONE;
         if (tcx.phase == 0) {
+            const bool mid = tstate == TS_AS;            // handed over in the middle of its first attempt: the row is complete
             const int np0 = w.npol[inst];
-            npol = np0 < 0 ? -np0 : np0; pass_in_attempt = 0;
-            pol_mu = c.polish_mu * T(1e-2);
             const T gb0 = w.gbase[inst];
-            gbase = fabs(gb0);
-            warm_avail = valid && gb0 < T(0);
+            if (!mid) { npol = np0 < 0 ? -np0 : np0; pass_in_attempt = 0; gbase = fabs(gb0); }
+            pol_mu = c.polish_mu * (mid ? T(1) : T(1e-2));
+            warm_avail = valid && !mid && gb0 < T(0);
             mu = c.mu0; rho = T(1); step_last = 0;
             if (__ballot(warm_avail) != 0) {
                 tIV = warm_avail ? tIV_own : tIV_spare;
@@ -1340,9 +1344,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 mu = ms / nc;
                 __syncthreads();
             }
-            tstate = valid ? (warm_avail ? (int)TS_IPM : (int)TS_FALLBACK) : (int)TS_NONE;
+            tstate = valid ? (mid ? (int)TS_AS : (warm_avail ? (int)TS_IPM : (int)TS_FALLBACK)) : (int)TS_NONE;
             warm_avail = false;
-            it = 1;               // the iteration the next launches perform
+            it = mid ? 0 : 1;     // the iteration the next launches perform
         } else if (tcx.phase == 1) {
             const bool ipm = tstate == TS_IPM;
             if (__ballot(ipm) != 0) {
@@ -1389,10 +1393,31 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             if (__ballot(mode == M_POL) != 0) {
                 nopins_pass = false;
                 k_top = N - 1; ck_valid = 0;
+                const bool first_attempt = npol < polish_passes;      // (a second attempt starts with all passes of the first one spent)
                 as_pass();
-                if (tstate == TS_AS) tstate = mode == M_DONE ? (int)TS_DONE : (mode == M_POL ? (int)TS_AS : (int)TS_FALLBACK);
+                // the first attempt ends in here when the first launch handed it over running: the hand-over the active-set kernel
+                // would have written (the fallback list relies on it), and the warm start becomes the interior point's iterate
+                const bool ended = tstate == TS_AS && mode == M_GIVEUP && first_attempt;
+                if (ended && r == 0) {
+                    w.npol[inst] = -(tripped ? c.polish_budget : npol);
+                    w.gbase[inst] = warm_avail ? -gbase : gbase;
+                }
+                const bool install = ended && warm_avail;
+                if (__ballot(install) != 0) {
+                    __syncthreads();
+                    tIV = install ? tIV_own : tIV_spare;
+                    sweepW(Ipm{});
+                    sh[r] = msF;
+                    __syncthreads();
+                    T ms = 0;
+                    NMPC_UNROLL for (int i = 0; i < 16; i++) ms += sh[i];
+                    if (install) { mu = ms / nc; rho = T(1); step_last = 0; it = 1; pol_mu = c.polish_mu * T(1e-2); pass_in_attempt = 0; }
+                    __syncthreads();
+                }
+                if (tstate == TS_AS) tstate = mode == M_DONE ? (int)TS_DONE : (mode == M_POL ? (int)TS_AS : (install ? (int)TS_IPM : (int)TS_FALLBACK));
                 tail_fin = tstate == TS_DONE && status == 0;
                 if (tstate == TS_DONE && status != 0) tstate = TS_FALLBACK;
+                warm_avail = false;
             }
             mode = M_DONE;
         }
@@ -1401,6 +1426,10 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 const int slot = atomicAdd(tcx.fb_count, 1);
                 tcx.fb_list[slot] = inst;
                 tstate = TS_LISTED;
+            }
+            if (tstate == TS_AS || tstate == TS_IPM) {
+                const int slot = atomicAdd(tcx.nx_count, 1);
+                tcx.nx_list[slot] = inst;
             }
             tsr[0] = (T)tstate; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase; tsr[4] = mu; tsr[5] = rho;
             tsr[6] = (T)it; tsr[7] = pol_mu; tsr[8] = step_last;
@@ -1571,6 +1600,17 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     tLM = tLM_own; tIV = tIV_own;
     if (!valid) return;
     if (MODE == 3 && !tail_fin) return;          // the instance is still in the tail, or went to the fallback list
+    if (MODE == 0 && mode == M_POL) {
+        // the attempt is still running (pass cap of a long-horizon solve): its state goes to the tail's row - the pins of the next
+        // pass are in the workspace already
+        if (r == 0) {
+            T *tsr = tcx.ts + (size_t)inst * TS_ROWS;
+            tsr[0] = (T)TS_AS; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase;
+            const int slot = atomicAdd(wl.count, 1);
+            wl.list[slot] = inst;
+        }
+        return;
+    }
     if (MODE == 0 && mode == M_GIVEUP) {
         if (r == 0) {
             // the work-list launch resumes the pass budget from here (all of it spent when the growth certificate ended the
