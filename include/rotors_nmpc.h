@@ -263,7 +263,8 @@ int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void
  * into qp_solver_cond_N = min(N, 5) blocks; cfg/rotors_mpc.cfg:9 lets the horizon reach 600).  The horizon is cut into `blocks`
  * blocks that are swept by their own teams AT THE SAME TIME, with `blocks - 1` sequential boundary updates in between
  * (csrc/nmpc_block.hpp has the algebra) - the blocks of the reference's condensing, used as parallelism instead of as 480-input
- * dense stages.  Building block and diagnostic: it is not on the path of nmpc_solve_batch* yet.
+ * dense stages.  A building block with its own entry point; nmpc_solve_batch* uses the same kernels by itself from N = 256 up
+ * (the block-parallel tail of long-horizon solves).
  *   The LQ problem factorised is the one the LAST solve of this handle ended on - its per-stage linearisation (so that solve must
  *   have been warm-started, or NMPC_FLAG_SHARE_COLD_START off) and the pin set its last forward sweep left; x0 .. u_init are the
  *   device arrays that solve was given.  FP64 arithmetic in the team mapping only.

@@ -28,7 +28,8 @@
 // conditioning of the boundary update; tests/test_gpu_block.py compares them at N = 600.
 //
 // The stage below is the pins variant of sweepA's stage in nmpc_team_as.hpp (same products, same order), restated here because
-// that one is a lambda over the solver's pass state; nothing of this file is on the default solve path yet.
+// that one is a lambda over the solver's pass state.  Used by nmpc_block_factor_device (a building block with its own entry point)
+// and, in tail mode, by every long-horizon solve (N >= 256: the block-parallel tail).
 #pragma once
 
 #include "nmpc_ipm.hpp"
