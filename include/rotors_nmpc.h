@@ -263,7 +263,7 @@ int nmpc_kkt_report_device(nmpc_solver *s, int B, const void *x_traj, const void
  * into qp_solver_cond_N = min(N, 5) blocks; cfg/rotors_mpc.cfg:9 lets the horizon reach 600).  The horizon is cut into `blocks`
  * blocks that are swept by their own teams AT THE SAME TIME, with `blocks - 1` sequential boundary updates in between
  * (csrc/nmpc_block.hpp has the algebra) - the blocks of the reference's condensing, used as parallelism instead of as 480-input
- * dense stages.  A building block with its own entry point; nmpc_solve_batch* uses the same kernels by itself from N = 256 up
+ * dense stages.  A building block with its own entry point; nmpc_solve_batch* uses the same kernels by itself from N = 160 up
  * (the block-parallel tail of long-horizon solves).
  *   The LQ problem factorised is the one the LAST solve of this handle ended on - its per-stage linearisation (so that solve must
  *   have been warm-started, or NMPC_FLAG_SHARE_COLD_START off) and the pin set its last forward sweep left; x0 .. u_init are the
@@ -283,7 +283,7 @@ int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out);
 
 /* diagnostic: where the block-parallel tail of long-horizon solves (csrc/nmpc_block.hpp) left the instances
  * of the last solve: host_out [B] = 0 not in the work list, 3 finished by the tail, 5 handed on to the sequential work-list kernel.
- * Returns the number of blocks the tail cuts the horizon into (0: this handle runs no tail - N < 256 unless NMPC_BLOCK_TAIL=1) */
+ * Returns the number of blocks the tail cuts the horizon into (0: this handle runs no tail - N < 160 unless NMPC_BLOCK_TAIL=1) */
 int nmpc_debug_tail_states(nmpc_solver *s, int B, int32_t *host_out);
 
 /* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */

@@ -148,7 +148,8 @@ struct nmpc_solver {
     double *blk_agg = nullptr, *blk_bnd = nullptr, *blk_chk = nullptr, *blk_fac = nullptr;
     int blk_J = 0;
     hipEvent_t blk_ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    // block-parallel tail of long-horizon solves: NMPC_BLOCK_TAIL = 0 off | 1 on | unset: on from N = 256 up;
+    // block-parallel tail of long-horizon solves: NMPC_BLOCK_TAIL = 0 off | 1 on | unset: on from N = 160 up (measured at B = 1024: N = 120 0.24 -> 0.46 ms,
+    // 150 0.72 -> 0.70, 180 1.46 -> 1.18, 250 3.33 -> 2.29, 600 17.2 -> 10.1);
     // NMPC_BLOCK_J = blocks (unset: ~0.7 sqrt(N): measured optimum of config 5, 10.0 ms at J = 16-17 against 10.3 at 21 and 10.6 at 10)
     int block_tail = -1, block_J = 0, tail_cap = 1;   // NMPC_TAIL_CAP: passes of the first attempt the first launch performs itself
     int tail_J = 0, tail_M = 0;      // blocks that hold stages, stages per block (0: the tail is not used by this handle)
@@ -374,7 +375,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         const bool can = g.dtype != NMPC_DTYPE_F32 && (g.flags & NMPC_FLAG_TEAM_MAPPING) && !(g.flags & NMPC_FLAG_CONDENSED_QP) && g.qp_polish &&
                          g.qp_warm_start && g.qp_polish_budget > g.qp_polish_passes && g.qp_polish_budget <= 2 * g.qp_polish_passes &&
                          g.sim_num_steps <= AS_MAX_STEPS && s->team_qp && s->team_split && s->team_mfma && g.N >= 8;
-        const bool want = s->block_tail < 0 ? g.N >= 256 : s->block_tail != 0;
+        const bool want = s->block_tail < 0 ? g.N >= 160 : s->block_tail != 0;
         if (can && want) {
             int J = s->block_J > 0 ? s->block_J : (int)std::lround(0.7 * std::sqrt((double)g.N));
             J = std::max(2, std::min(J, g.N / 2));
