@@ -589,7 +589,10 @@ def main() -> None:
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + st.get("ms_tail", 0.0), prepare_ms=st["ms_prepare"],
                       launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=st["ms_tail"],
                                      instances_in_second_launch=st["n_tail"],
-                                     note="kernel_ms = device time of one step = both launches (HIP events around the timed region)")
+                                     note=("kernel_ms = device time of one step = both launches (HIP events around the timed region)" if N < 160 or os.environ.get("NMPC_BLOCK_TAIL") == "0"
+                                           else "long horizon: k_team_as = preparation + first pass; the second figure is every later launch (block-parallel tail: "
+                                                "k_block_sweep_tail / k_block_scan_tail / k_team_tail per step, then k_team_qp_list on the fallback list); "
+                                                "instances_in_second_launch counts the instances that took an interior-point iteration"))
                                 if split else None), hbm=hbm, alu=flop)
         if mfma_path:
             roof = dict(bound="mfma", achieved=alu_x_tf, peak=f_peak, unit="TFLOP/s", frac=alu_x_tf / f_peak, **common)
