@@ -39,6 +39,7 @@ namespace nmpc {
 
 constexpr int BLK_FAC_ROWS = 80;     // factors of one stage: Mbar' as 4 tiles x 16 lanes (64) | L^-1 tile (16)
 constexpr int BLK_MAT = 256;         // a 16 x 16 matrix as 16 tiles x 16 lanes
+constexpr int BLK_GB = 384;          // what the scan keeps of a boundary for its forward pass: 24 tiles x 16 lanes
 constexpr int BLK_LDS = 56;          // doubles of LDS per team (gradient row 16 | zero slot | pad | 4 x 4 exchange 16): 192 B past a bank row
 
 struct BlockWork {
@@ -58,6 +59,9 @@ struct BlockWork {
     double *tLM;           // [Bp + 1][N][TLM_ROWS]
     double *binfo;         // [Bp + 1][J][2] per block: max |B'PB| of the final sweep | 0 ok, 1 pivot not positive, 2 NaN pivot
     int shared;            // one linearisation for all stages: tiles of stage 0
+    // block-parallel forward sweep (tail mode): the scan also leaves the state at the start of every block
+    double *gbuf;          // [Bp + 1][J][384]      factors of the boundary behind block j the scan's forward pass needs (or null: no forward pass)
+    double *xb;            // [Bp + 1][J][16]       xbar at the start of block j
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -524,6 +528,19 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
                 }
             }
         }
+        if (g.gbuf) {
+            // what the forward pass below needs of this boundary: L (10 tiles), Le' (6), Le_ii^-T (4), 1 / de (4 per-lane values)
+            T *gp = g.gbuf + (winst * g.J + blk) * BLK_GB + r;
+            int q = 0;
+            NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                NMPC_UNROLL for (int m = k; m < 4; m++) gp[(q++) * 16] = Lm[m][k];
+            }
+            NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                NMPC_UNROLL for (int m = k + 1; m < 4; m++) gp[(q++) * 16] = le.LT[k][m];
+            }
+            NMPC_UNROLL for (int k = 0; k < 4; k++) gp[(q++) * 16] = le.Yd[k];
+            NMPC_UNROLL for (int k = 0; k < 4; k++) gp[(q++) * 16] = le.ra[k];
+        }
         // P_s = J + Z' De^-1 Z
         NMPC_UNROLL for (int k = 0; k < 4; k++) {
             NMPC_UNROLL for (int l = k; l < 4; l++) {
@@ -539,6 +556,56 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
         T *bp = g.bnd + (winst * (g.J + 1) + blk) * BLK_MAT + r;
         NMPC_UNROLL for (int it = 0; it < 4; it++) {
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) bp[(it * 4 + jt) * 16] = ok ? Pe[it][jt] : __builtin_nan("");
+        }
+    }
+    if (g.gbuf) {
+        // forward over the boundaries: xbar at the start of every block (stage 0: the deviation from x0 is zero, xbar = e15).
+        //   xbar_e = (I + C P_e)^-1 Psi xbar_s = y - C L Le^-T De^-1 Le^-1 L' y,   y = Psi xbar_s
+        // as six matrix-vector products on tiles (a vector sits in column 0 of its four tiles); every operand tile is read from
+        // memory in the orientation its product needs (a transposed tile is the same 16 doubles through the swapped lane index)
+        __syncthreads();                      // the tiles above were written by other lanes of this team
+        T xt[4];
+        NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+        T *xp = g.xb + winst * g.J * 16;
+        for (int blk = 0; blk < g.J; blk++) {
+            if (tc == 0) { NMPC_UNROLL for (int t = 0; t < 4; t++) xp[blk * 16 + t * 4 + ta] = xt[t]; }
+            if (blk == g.J - 1) break;
+            const T *ap = g.agg + (winst * g.J + blk) * 3 * BLK_MAT;
+            const T *gp = g.gbuf + (winst * g.J + blk) * BLK_GB;
+            // tile index of L[m][k] (m >= k), of Le'[k][m] (m > k), of Le_kk^-T, of 1 / de in the boundary's slot
+            auto iL = [](int m, int k) { return (k == 0 ? 0 : (k == 1 ? 4 : (k == 2 ? 7 : 9))) + (m - k); };
+            auto iE = [](int k, int m) { return 10 + (k == 0 ? 0 : (k == 1 ? 3 : 5)) + (m - k - 1); };
+            T y1[4], y2[4], y3[4], y5[4], y6[4];
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y1 = Psi x: a = Psi[i][k]' = Phi[k][i] as stored
+                T a = 0;
+                NMPC_UNROLL for (int k = 0; k < 4; k++) a = mfma44(ap[BLK_MAT + (k * 4 + i) * 16 + r], xt[k], a);
+                y1[i] = a;
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y2 = L' y1: a = L[n][i]
+                T a = 0;
+                NMPC_UNROLL for (int n = i; n < 4; n++) a = mfma44(gp[iL(n, i) * 16 + r], y1[n], a);
+                y2[i] = a;
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y3 = Le^-1 y2 (forward substitution): a = Le'[m][i], Le_ii^-T
+                T a = y2[i];
+                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m < i) a = mfma44(-gp[iE(m, i) * 16 + r], y3[m], a); }
+                y3[i] = mfma44(gp[(16 + i) * 16 + r], a, T(0));
+            }
+            NMPC_UNROLL for (int i = 3; i >= 0; i--) {            // y5 = Le^-T De^-1 y3 (back substitution): a = (Le'[i][m])' , (Le_ii^-T)'
+                T a = gp[(20 + i) * 16 + r] * y3[i];
+                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m > i) a = mfma44(-gp[iE(i, m) * 16 + rT], y5[m], a); }
+                y5[i] = mfma44(gp[(16 + i) * 16 + rT], a, T(0));
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y6 = L y5: a = L[i][m]'
+                T a = 0;
+                NMPC_UNROLL for (int m = 0; m <= i; m++) a = mfma44(gp[iL(i, m) * 16 + rT], y5[m], a);
+                y6[i] = a;
+            }
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // x_e = y1 - C y6: a = C[m][i] (C symmetric)
+                T a = y1[i];
+                NMPC_UNROLL for (int m = 0; m < 4; m++) a = mfma44(-ap[2 * BLK_MAT + (m * 4 + i) * 16 + r], y6[m], a);
+                xt[i] = a;
+            }
         }
     }
 }

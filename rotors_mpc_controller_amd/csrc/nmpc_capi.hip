@@ -154,6 +154,8 @@ struct nmpc_solver {
     int block_tail = -1, block_J = 0, tail_cap = 1;   // NMPC_TAIL_CAP: passes of the first attempt the first launch performs itself
     int tail_J = 0, tail_M = 0;      // blocks that hold stages, stages per block (0: the tail is not used by this handle)
     double *d_ts = nullptr, *d_binfo = nullptr, *tail_agg = nullptr, *tail_bnd = nullptr;
+    double *tail_gbuf = nullptr, *tail_xb = nullptr, *tail_frec = nullptr;   // block-parallel forward sweep (NMPC_TAIL_FWD=0: sequential)
+    int tail_fwd = 1;
     int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
     int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
@@ -357,6 +359,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_BLOCK_TAIL")) s->block_tail = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_BLOCK_J")) s->block_J = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TAIL_CAP")) s->tail_cap = std::atoi(e);
+    if (const char *e = std::getenv("NMPC_TAIL_FWD")) s->tail_fwd = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -387,7 +390,10 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
                       hipMalloc((void **)&s->tail_agg, Bw * J * 3 * BLK_MAT * sizeof(double)) == hipSuccess &&
                       hipMalloc((void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
                       hipMalloc((void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
-                      hipMalloc((void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess;
+                      hipMalloc((void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                      hipMalloc((void **)&s->tail_gbuf, Bw * J * BLK_GB * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->tail_xb, Bw * J * 16 * sizeof(double)) == hipSuccess &&
+                      hipMalloc((void **)&s->tail_frec, Bw * J * FR_ROWS * sizeof(double)) == hipSuccess;
             ok = ok && hipMemset(s->d_wl2, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_wl3, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_ts, 0, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
@@ -425,7 +431,8 @@ void nmpc_destroy(nmpc_solver *s)
     for (void *p : ptrs)
         if (p) (void)hipFree(p);
     for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac, (void *)s->d_ts, (void *)s->d_binfo,
-                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3})
+                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3, (void *)s->tail_gbuf, (void *)s->tail_xb,
+                    (void *)s->tail_frec})
         if (p) (void)hipFree(p);
     for (auto &e : s->blk_ev)
         if (e) (void)hipEventDestroy(e);
@@ -522,13 +529,14 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         tl.lds_stride = tl.lm_off + (24 - tl.lm_off % 32 + 32) % 32;
         tl.lds_bytes = (size_t)4 * tl.lds_stride * sizeof(double);
         tl.tail.ts = s->d_ts; tl.tail.binfo = s->d_binfo; tl.tail.J = s->tail_J; tl.tail.fb_count = wl2.count; tl.tail.fb_list = wl2.list;
-        BlockLaunch bl;
+        BlockLaunch bl{};
         bl.cp = al.cp;
         bl.g.tAB = (const double *)s->tAB; bl.g.tIV = (const double *)s->iv;
         bl.g.agg = s->tail_agg; bl.g.bnd = s->tail_bnd; bl.g.bchk = nullptr; bl.g.fac = nullptr;
         bl.g.Bp = s->Bp; bl.g.B = B; bl.g.J = s->tail_J; bl.g.M = s->tail_M;
         bl.g.list = wl.list; bl.g.count = wl.count; bl.g.ts = s->d_ts; bl.g.tLM = (double *)s->LM; bl.g.binfo = s->d_binfo;
         bl.g.shared = c.shared != 0;
+        bl.g.gbuf = s->tail_fwd ? s->tail_gbuf : nullptr; bl.g.xb = s->tail_xb;
         bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
         for (auto &e : bl.ev) e = nullptr;
         // the work list is compacted from step to step: every step reads one list and appends what is still in the tail to the other
@@ -544,6 +552,14 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
                 // the list this step appends to was consumed by the previous step: its count is zeroed between the two block sweeps
                 bl.g.reset_count = lists[cur ^ 1].count;
                 HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+            }
+            tl.tail.frec = nullptr;
+            if (phase == 2 && s->tail_fwd) {
+                // forward sweep of the pass: the blocks of every instance at the same time (phase 3), then the decision (phase 2)
+                tl.tail.frec = s->tail_frec; tl.tail.xb = s->tail_xb; tl.tail.M = s->tail_M;
+                tl.tail.phase = 3;
+                HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+                tl.tail.phase = 2;
             }
             HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
             cur ^= 1;
@@ -1126,7 +1142,7 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
         for (auto &e : s->blk_ev)
             if (!e) HIP_TRY(s, hipEventCreate(&e));
     }
-    BlockLaunch bl;
+    BlockLaunch bl{};
     bl.cp = (const Consts<double> *)s->d_consts;
     bl.g.tAB = (const double *)s->tAB; bl.g.tIV = (const double *)s->iv;
     bl.g.agg = s->blk_agg; bl.g.bnd = s->blk_bnd; bl.g.bchk = check_out ? s->blk_chk : nullptr; bl.g.fac = s->blk_fac;

@@ -77,15 +77,17 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
         const int e = base + team;
         const int inst = e < n ? wl.list[e] : -1;
         const int st = inst >= 0 ? (int)tcx.ts[(size_t)inst * TS_ROWS] : (int)TS_NONE;
-        const bool act = inst >= 0 && (tcx.phase == 0 || (tcx.phase == 1 && st == TS_IPM) || (tcx.phase == 2 && st == TS_AS));
+        const bool act = inst >= 0 && (tcx.phase == 0 || (tcx.phase == 1 && st == TS_IPM) || ((tcx.phase == 2 || tcx.phase == 3) && st == TS_AS));
         // an instance that is in the tail but not part of this phase stays on the (compacted) list of the next step
-        if (inst >= 0 && !act && (st == TS_IPM || st == TS_AS) && (threadIdx.x & 0x33) == 0) {
+        if (tcx.phase != 3 && inst >= 0 && !act && (st == TS_IPM || st == TS_AS) && (threadIdx.x & 0x33) == 0) {
             const int slot = atomicAdd(tcx.nx_count, 1);
             tcx.nx_list[slot] = inst;
         }
         if (__ballot(act) == 0) continue;
+        TailCtx tc2 = tcx;
+        tc2.blk = blockIdx.y;                  // (phase 3: one block of the horizon per team; the grid's y dimension is 1 otherwise)
         team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
-                                           act ? inst : -1, tcx);
+                                           act ? inst : -1, tc2);
         __syncthreads();
     }
 }
@@ -100,7 +102,7 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
         return (int)hipGetLastError();
     }
     if (a.kind == 3) {
-        const dim3 grid(a.nlist), block(64);
+        const dim3 grid(a.nlist, a.tail.phase == 3 ? a.tail.J : 1), block(64);
 #define NMPC_LAUNCH_TL(SH_, TR_) hipLaunchKernelGGL((k_team_tail<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.lds_stride, a.lm_off, a.tail)
         if (a.shared) { if (a.traj) NMPC_LAUNCH_TL(true, true); else NMPC_LAUNCH_TL(true, false); }
         else { if (a.traj) NMPC_LAUNCH_TL(false, true); else NMPC_LAUNCH_TL(false, false); }

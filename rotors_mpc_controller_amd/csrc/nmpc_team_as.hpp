@@ -98,9 +98,13 @@ struct TailCtx {
     const double *binfo = nullptr;   // [Bp + 1][J][2] verdict of the block factorisation of this step (nmpc_block.hpp)
     int J = 0;
     int phase = 0;                   // 0: install the warm start | 1: the rest of an interior-point iteration | 2: the rest of an active-set pass
+                                     // 3: forward sweep of ONE block of an active-set pass (then phase 2 only decides)
     int *fb_count = nullptr;         // fallback list: what the tail does not finish (solved by k_team_qp_list from the hand-over)
     int *fb_list = nullptr;
     int cap = 0;                     // MODE 0: passes the first launch performs before it hands a running attempt to the tail (0: all)
+    double *frec = nullptr;          // [Bp + 1][J][FR_ROWS] records of the block-parallel forward sweep (phase 3 writes, phase 2 reads), or null
+    const double *xb = nullptr;      // [Bp + 1][J][16] state at the start of every block (left by the boundary scan)
+    int blk = 0, M = 0;              // phase 3: this team's block, stages per block
     int *nx_count = nullptr;         // the work list of the NEXT step: instances that are still in the tail after this one (the list is
     int *nx_list = nullptr;          // compacted from step to step: a wave costs the same with one live team as with four)
 };
@@ -654,6 +658,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             stage(0, Tr{}, Fl{});
         }
     };
+    // range and start state of the forward sweep (MODE 3, block-parallel forward: one team sweeps one block; otherwise the horizon)
+    int fwd_s = 0, fwd_e = N;
+    const T *fwd_x = nullptr;
     // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
     // is one basic block; operands arrive two stages ahead in two alternating register sets
     auto sweepB = [&](auto pins_tag, auto ipm_tag, auto warm_tag) {
@@ -675,6 +682,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         if (SHARED) load_tiles_T();
         T xt[4];
         NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
+        if (MODE == 3 && fwd_x) {             // block-parallel forward sweep: the state at the start of this team's block (lanes (a,0))
+            NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = tc == 0 ? fwd_x[t * 4 + ta] : T(0);
+        }
         // lanes (a, c != 0) carry no part of xbar / u: their stores go to spare slots (xhat pad slot 13, tIV slot 0)
         int xslot[4];
         NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
@@ -800,7 +810,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         constexpr int H = 2;
         constexpr bool PRE = false;
         Ops oa[H], ob[H];
-        const int kb = SHARED ? kl : 0;                      // first stage of the main loop
+        const int kb = MODE == 3 ? fwd_s : (SHARED ? kl : 0);   // first stage of the main loop
+        const int fe = MODE == 3 ? fwd_e : N;                   // ... and the stage behind its last (MODE 3: this team's block)
         NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + i, oa[i]);
         if (PRE) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(kb + H + i, ob[i]); }
         if constexpr (LDSC && SHARED) {
@@ -840,11 +851,11 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 }
             }
         }
-        for (int k0 = kb; k0 < N; k0 += 2 * H) {
+        for (int k0 = kb; k0 < fe; k0 += 2 * H) {
             if (!PRE || k0 != kb) { NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + H + i, ob[i]); }
-            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + i < N) stageB(k0 + i, oa[i]); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + i < fe) stageB(k0 + i, oa[i]); }
             NMPC_UNROLL for (int i = 0; i < H; i++) fetch_ops(k0 + 2 * H + i, oa[i]);
-            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + H + i < N) stageB(k0 + H + i, ob[i]); }
+            NMPC_UNROLL for (int i = 0; i < H; i++) { if (k0 + H + i < fe) stageB(k0 + H + i, ob[i]); }
         }
         // back to one natural row per lane
         if (tc == 0) {
@@ -1269,7 +1280,20 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         // ... and a later attempt is still allowed: the warm start is for the interior-point iteration BETWEEN two attempts
         const bool warm_ok = pass_in_attempt == polish_passes - 1 && npol - pass_in_attempt + polish_passes < c.polish_budget;
         const bool lastp = c.warm_start != 0 && __ballot(pol2 && warm_ok) != 0;
-        if (nopins_pass) sweepB(NoPins{}, NoIpm{}, NoWarm{});
+        if (MODE == 3 && tcx.frec) {
+            // the blocks of the horizon swept forward at the same time (phase 3): their records stand in for the sweep
+            const T *fr = tcx.frec + (size_t)(pol2 ? (size_t)inst : (size_t)w.Bp) * tcx.J * FR_ROWS;
+            int kcm = -1;
+            for (int b = 0; b < tcx.J; b++) {
+                viol |= fr[b * FR_ROWS] != T(0); heavy |= fr[b * FR_ROWS + 1] != T(0); anyp |= fr[b * FR_ROWS + 3] != T(0);
+                const int kb_ = (int)fr[b * FR_ROWS + 2];
+                kcm = kb_ > kcm ? kb_ : kcm;
+            }
+            u0_cand = pol2 ? fr[4 + ta] : u0_cand;
+            xh = fr[(tcx.J - 1) * FR_ROWS + 8 + rr];
+            if (tc == 0) sRed[28 + ta] = (T)kcm;
+        }
+        else if (nopins_pass) sweepB(NoPins{}, NoIpm{}, NoWarm{});
         else if (lastp) sweepB(WithPins{}, NoIpm{}, Warm{});
         else sweepB(WithPins{}, NoIpm{}, NoWarm{});
         NMPC_STAMP(1)
@@ -1388,6 +1412,34 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 pass_in_attempt = 0;
                 __syncthreads();
             }
+        } else if (tcx.phase == 3) {
+            // forward sweep of block tcx.blk of an active-set pass (the blocks of an instance at the same time, from the states the
+            // boundary scan left): KKT check, pin codes, candidate inputs and - last pass of a first attempt - the warm start of
+            // its stages; what the decision of the pass needs goes to the block's record
+            mode = tstate == TS_AS ? M_POL : M_DONE;
+            if (__ballot(mode == M_POL) != 0) {
+                pol = mode == M_POL; pol2 = pol;
+                tLM = pol ? tLM_own : tLM_spare; tIV = pol ? tIV_own : tIV_spare; tP = tP_spare;
+                nopins_pass = false;
+                fwd_s = tcx.blk * tcx.M; fwd_e = fwd_s + tcx.M < N ? fwd_s + tcx.M : N;
+                fwd_x = tcx.xb + ((size_t)winst * tcx.J + tcx.blk) * 16;
+                viol = false; heavy = false; kchgB = -1; xh = 0; anyp = false;
+                const bool warm_ok = pass_in_attempt == polish_passes - 1 && npol - pass_in_attempt + polish_passes < c.polish_budget;
+                const bool lastp = c.warm_start != 0 && __ballot(pol2 && warm_ok) != 0;
+                if (lastp) sweepB(WithPins{}, NoIpm{}, Warm{});
+                else sweepB(WithPins{}, NoIpm{}, NoWarm{});
+                __syncthreads();
+                const bool t_viol = (__ballot(viol && tc == 0) & team_mask) != 0;
+                const bool t_heavy = (__ballot(heavy && tc == 0) & team_mask) != 0;
+                const bool t_anyp = (__ballot(anyp && tc == 0) & team_mask) != 0;
+                const int kc = (int)fmax(fmax(sRed[28], sRed[29]), fmax(sRed[30], sRed[31]));
+                T *fr = tcx.frec + ((size_t)winst * tcx.J + tcx.blk) * FR_ROWS;
+                if (r == 0) { fr[0] = t_viol ? T(1) : T(0); fr[1] = t_heavy ? T(1) : T(0); fr[2] = (T)kc; fr[3] = t_anyp ? T(1) : T(0); }
+                if (tc == 0) fr[4 + ta] = u0_cand;
+                if (rowl) fr[8 + rr] = xh;
+                __syncthreads();
+            }
+            mode = M_DONE;
         } else {
             mode = tstate == TS_AS ? M_POL : M_DONE;
             if (__ballot(mode == M_POL) != 0) {
@@ -1421,7 +1473,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             }
             mode = M_DONE;
         }
-        if (valid && r == 0) {
+        if (valid && r == 0 && tcx.phase != 3) {
             if (tstate == TS_FALLBACK) {
                 const int slot = atomicAdd(tcx.fb_count, 1);
                 tcx.fb_list[slot] = inst;

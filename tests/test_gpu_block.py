@@ -137,7 +137,9 @@ def test_block_parallel_tail_gives_the_results_of_the_sequential_work_list(N, B,
     np.testing.assert_array_equal(psa, psb)
     ok = a["status"] == 0
     np.testing.assert_allclose(b["u0"][ok], a["u0"][ok], rtol=0, atol=1e-9)
-    np.testing.assert_allclose(b["x"][ok], a["x"][ok], rtol=0, atol=1e-8)
+    # (trajectories: the tail's forward sweep starts every block from a state the boundary scan reconstructs - relative 1e-9 of states
+    # that reach hundreds of metres over a 30 s horizon)
+    np.testing.assert_allclose(b["x"][ok], a["x"][ok], rtol=1e-9, atol=1e-8)
     np.testing.assert_allclose(b["u"][ok], a["u"][ok], rtol=0, atol=1e-8)
     # second solve from the first one's trajectories: the per-stage linearisation through the same two paths
     if N <= 100:
