@@ -52,7 +52,13 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double>
         int inst;
         const bool act = tail_pick(g, base, n, inst);
         if (__ballot(act) == 0) continue;
-        if (phase == 1 && blk < g.J - 1) block_sweep<true, TI, true>(*cp, g, in, blk, smem, inst, act);
+        if (phase == 1 && blk < g.J - 1) {
+            // aggregate of a block: unchanged since the last pass of this attempt if no pin code of the block changed
+            const bool keep = act && g.frec && g.ts[(size_t)inst * TS_ROWS + 10] != 0.0 &&
+                              g.frec[((size_t)inst * g.J + blk) * FR_ROWS] == 0.0;
+            if (__ballot(act && !keep) == 0) continue;
+            block_sweep<true, TI, true>(*cp, g, in, blk, smem, inst, act && !keep);
+        }
         else block_sweep<false, TI, true>(*cp, g, in, blk, smem, inst, act);
         __syncthreads();
     }

@@ -62,6 +62,8 @@ struct BlockWork {
     // block-parallel forward sweep (tail mode): the scan also leaves the state at the start of every block
     double *gbuf;          // [Bp + 1][J][384]      factors of the boundary behind block j the scan's forward pass needs (or null: no forward pass)
     double *xb;            // [Bp + 1][J][16]       xbar at the start of block j
+    const double *frec;    // [Bp + 1][J][FR_ROWS]  records of the last pass's forward sweep (or null): a block whose pin codes did not change
+                           //                       keeps its aggregate - the zero-terminal sweep depends on nothing else
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)

@@ -74,6 +74,7 @@ constexpr int TS_ROWS = 16;
 enum { TS_NONE = 0, TS_IPM = 1, TS_AS = 2, TS_DONE = 3, TS_FALLBACK = 4, TS_LISTED = 5 };
 // [0] state  [1] passes spent  [2] passes of the attempt in flight  [3] growth reference  [4] mu  [5] rho  [6] interior-point iterations
 // [7] threshold of the next attempt  [8] last step  [9] the iterate descends from a warm start
+// [10] the block aggregates in memory belong to the pin set of the last pass (blocks whose pins did not change keep theirs)
 
 // record a block's forward sweep leaves for the decision of the pass (block-parallel forward sweep of the tail): FR_ROWS doubles per
 // (instance, block): [0] a pin code changed  [1] NaN seen  [2] highest stage with a changed pin code  [3] a pinned input met

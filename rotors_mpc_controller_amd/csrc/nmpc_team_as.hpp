@@ -1485,6 +1485,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             }
             tsr[0] = (T)tstate; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase; tsr[4] = mu; tsr[5] = rho;
             tsr[6] = (T)it; tsr[7] = pol_mu; tsr[8] = step_last;
+            // the next pass of the same attempt re-aggregates only the blocks in which a pin code changed (nmpc_block.hip)
+            tsr[10] = (tcx.phase == 2 && tcx.frec && tstate == TS_AS) ? T(1) : T(0);
         }
     } else {
         // ---- phases of a wave: interior-point iterations for the teams in that mode until each has converged, failed or
