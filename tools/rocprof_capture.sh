@@ -7,6 +7,7 @@ set -e
 TAG=${1:-r01}
 REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/rocprof_$TAG
+rm -rf $OUT      # (a merged-back copy of an earlier capture must not be summarised with this one)
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 ARGS="--steps 10 --warmup 2 --no-cpu-baseline --no-secondary ${BENCH_ARGS}"
