@@ -24,6 +24,8 @@
 //                             factorisations (T = L (Dp^-1 + L'C L)^-1 L' with P_e = L Dp L': symmetric positive definite
 //                             operations only, no cancellation; needs P_xx > 0, i.e. positive state weights)
 //   launch 3  k_block_sweep   blocks 0 .. J-2: the ordinary sweep from their boundary value, factors stored
+// and, for the forward sweep of a pass (tail mode): the scan walks the boundaries forward once more and leaves the state at the start
+// of every block, xbar_e = (I + C P_e)^-1 Psi xbar_s, so that the blocks can sweep forward at the same time too (k_team_tail phase 3).
 // The factors are the ones the sequential sweep of nmpc_team_as.hpp leaves (Mbar' tiles, L^-1 tile), equal to rounding times the
 // conditioning of the boundary update; tests/test_gpu_block.py compares them at N = 600.
 //
