@@ -56,50 +56,81 @@ def executed_flops(N: int, n_ipm: float, n_pass: float, shared: bool) -> float:
     return (1 if shared else N) * 7.7e3 + N * (n_ipm * 11.9e3 + n_pass * 10.07e3)
 
 
+def _physical_cores(allowed) -> int:
+    """Distinct (package, core) pairs among the hardware threads this process may run on (SMT siblings count once)."""
+    seen = set()
+    try:
+        for cpu in allowed:
+            base = Path(f"/sys/devices/system/cpu/cpu{cpu}/topology")
+            seen.add((int((base / "physical_package_id").read_text()), int((base / "core_id").read_text())))
+    except Exception:
+        return 0
+    return len(seen)
+
+
+def _timed_all_cores(solve, make_x0, cores: int, floor: int, target_s: float = 2.5, cap: int = 1 << 20):
+    """Rate of `solve` over all hardware threads on a sample sized to ~target_s of wall time (never below `floor` = 64 x
+    threads: every thread gets a run of instances long enough that scheduling and the first touch of its workspace do not
+    show).  Pass 1 (floor-sized) warms the thread pool and calibrates, pass 2 warms the sized sample, pass 3 is timed."""
+    x = make_x0(floor)
+    t = time.perf_counter(); solve(x, cores); rate = floor / (time.perf_counter() - t)
+    n = int(min(cap, max(floor, rate * target_s)))
+    x = make_x0(n)
+    solve(x, cores)
+    t = time.perf_counter(); res = solve(x, cores); dt = time.perf_counter() - t
+    return n / dt, n, res
+
+
 def cpu_baseline(B_sample: int, N: int):
     """Two CPU restatements on this box's host cores, bounded samples of the config-2 instances (seed 0):
     (1) the oracle (oracle/nmpc_oracle.c): dense, unstructured, readable - the parity checker, same algorithm as the GPU default
         (active-set passes + interior point);
     (2) the structured host build of the lane kernels' own bodies (tests/hostsim: sparse model Jacobians, packed Riccati
         recursion on the 7 dense columns of A, no dense 13x13 loops) - plain interior point, the algorithm class HPIPM runs.
-    Both are ports (`kind`), neither is acados: the reference's own CPU path cannot be built here."""
+    Both are ports (`kind`), neither is acados: the reference's own CPU path cannot be built here.
+    All-core figures: no allocation inside a solve (per-thread arenas / workspaces), static schedule, samples of >= 64 instances
+    per hardware thread sized to ~2.5 s, two warm-up passes; `scaling_efficiency` = value / (threads x single-thread value)."""
     from oracle import oracle as O
     from rotors_mpc_controller_amd import _lib
     from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
     c = O.default_config(N=N, qp_gamma=0.0, qp_polish=1)      # same algorithm as the GPU default
     yref, ye = O.hover_yref(c)
     x0 = sample_x0(B_sample, 0, **NEAR_HOVER)
-    cores = len(os.sched_getaffinity(0))
-    O.solve_batch(c, x0[:64], yref, ye, nthreads=cores)       # warm the pool
+    allowed = sorted(os.sched_getaffinity(0))
+    cores = len(allowed)
+    phys = _physical_cores(allowed)
+    out = O.solve_batch(c, x0, yref, ye, nthreads=cores)      # the parity sample (also warms the pool)
+    mk = lambda n: sample_x0(n, 0, **NEAR_HOVER)
+    rate, n_all, _ = _timed_all_cores(lambda x, nt: O.solve_batch(c, x, yref, ye, nthreads=nt), mk, cores, max(64 * cores, 4096))
+    n1 = 4096
+    x1 = mk(n1)
+    O.solve_batch(c, x1[:256], yref, ye, nthreads=1)
     t = time.perf_counter()
-    out = O.solve_batch(c, x0, yref, ye, nthreads=cores)
-    dt_all = time.perf_counter() - t
-    n1 = max(64, B_sample // max(cores, 1))
-    t = time.perf_counter()
-    O.solve_batch(c, x0[:n1], yref, ye, nthreads=1)
-    dt_1 = time.perf_counter() - t
-    row = dict(value=B_sample / dt_all, unit="solves/s", cores=cores, kind="port",
-               sample=f"{B_sample} of the config-2 instances (seed 0), OpenMP over instances, "
-                      f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM)",
-               single_thread_value=n1 / dt_1)
+    O.solve_batch(c, x1, yref, ye, nthreads=1)
+    r1 = n1 / (time.perf_counter() - t)
+    smt = f"{cores} hardware threads on {phys} physical cores" if phys and phys != cores else f"{cores} cores"
+    row = dict(value=rate, unit="solves/s", cores=cores, physical_cores=phys or None, kind="port",
+               sample=f"{n_all} near-hover instances (config-2 recipe, seed 0), OpenMP static schedule over instances, "
+                      f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM); third of three passes",
+               single_thread_value=r1, scaling_efficiency=rate / (cores * r1),
+               note=f"{smt}; efficiency is against hardware threads (two SMT threads share one core's FP64 units: "
+                    f"~0.5-0.6 is then the ceiling)")
     try:
         from tests import hostsim as H
         cfg = _lib.default_config(N=N, flags=_lib.FLAG_SHARE_COLD_START)
         yr, yre = hover_reference(N, cfg.mass * cfg.gravity / 4.0)
-        Bs = 4 * B_sample                                     # ~10x faster per solve than the oracle: a larger sample for a stable figure
-        xs = sample_x0(Bs, 0, **NEAR_HOVER)
-        chk = H.solve_batch(cfg, x0, yr, yre, nthreads=cores)            # warm-up = the check: the oracle's own sample
+        chk = H.solve_batch(cfg, x0, yr, yre, nthreads=cores)            # the check: the oracle's own parity sample
+        rs, ns_all, hs = _timed_all_cores(lambda x, nt: H.solve_batch(cfg, x, yr, yre, nthreads=nt), mk, cores, max(64 * cores, 4096))
+        H.solve_batch(cfg, x1[:256], yr, yre, nthreads=1)
         t = time.perf_counter()
-        hs = H.solve_batch(cfg, xs, yr, yre, nthreads=cores)
-        ds_all = time.perf_counter() - t
-        n1 = max(256, Bs // max(cores, 1))
-        t = time.perf_counter()
-        H.solve_batch(cfg, xs[:n1], yr, yre, nthreads=1)
-        ds_1 = time.perf_counter() - t
+        H.solve_batch(cfg, x1, yr, yre, nthreads=1)
+        rs1 = n1 / (time.perf_counter() - t)
         ok = (chk["status"] == 0) & (out["status"] == 0)
-        row["structured"] = dict(value=Bs / ds_all, unit="solves/s", cores=cores, kind="port", single_thread_value=n1 / ds_1,
-                                 sample=f"{Bs} of the config-2 instances (seed 0), OpenMP over instances, host build of the lane kernel "
-                                        f"bodies nmpc_lane.hpp / nmpc_ipm.hpp (tests/hostsim): structured Riccati, plain interior point",
+        row["structured"] = dict(value=rs, unit="solves/s", cores=cores, physical_cores=phys or None, kind="port", single_thread_value=rs1,
+                                 scaling_efficiency=rs / (cores * rs1),
+                                 sample=f"{ns_all} near-hover instances (config-2 recipe, seed 0), OpenMP static schedule over chunks of 8 lanes in "
+                                        f"thread-private workspaces, host build of the lane kernel bodies nmpc_lane.hpp / nmpc_ipm.hpp "
+                                        f"(tests/hostsim): structured Riccati, plain interior point; third of three passes",
                                  ipm_iterations_mean=float(hs["iters"].mean()),
                                  max_abs_u0_vs_oracle=float(np.abs(chk["u0"][ok] - out["u0"][ok]).max()),
                                  note="plain interior point to mu <= 1e-11 (no active-set shortcut: ~8x the factorisations of row 1 on this "
@@ -452,13 +483,22 @@ def main() -> None:
         def eager_step():
             tick_ops(0, stream.cuda_stream)
 
-        def fence():
-            for _ in range(carry[0]):                            # ticks counted but not yet replayed
+        def drain():
+            # ticks counted but not yet replayed (steps % graph_ticks of them): run eagerly.  Called BEFORE the closing event of
+            # the timed region, so that device_ms_per_step and roofline.frac of a multi-rank line cover every tick (round 3 ran them
+            # inside fence(), after the event: 4 of the driver's 20 steps were missing from the device time of an N > 1 line)
+            for _ in range(carry[0]):
                 tick_ops(0, stream.cuda_stream)
             carry[0] = 0
+
+        def fence():
+            drain()
             dist.barrier()
             torch.cuda.synchronize(dev)
     else:
+        def drain():
+            pass
+
         u0g = [torch.zeros(G, B, 4, dtype=tdt, device=dev) for _ in range(2)]
         gathered = [torch.zeros(world, G, B, 4, dtype=tdt, device=dev) for _ in range(2)] if use_dist else None
         pending = [None, None]
@@ -512,6 +552,7 @@ def main() -> None:
     ev0.record(stream)
     for _ in range(args.steps):
         step()
+    drain()                                                      # every tick of the timed region is enqueued before the closing event
     ev1.record(stream)
     fence()
     elapsed = time.perf_counter() - t0

@@ -286,6 +286,13 @@ int nmpc_debug_factors(nmpc_solver *s, int B, double *host_out);
  * Returns the number of blocks the tail cuts the horizon into (0: this handle runs no tail - N < 160 unless NMPC_BLOCK_TAIL=1) */
 int nmpc_debug_tail_states(nmpc_solver *s, int B, int32_t *host_out);
 
+/* diagnostic: canary bands around every device buffer of the handle.  A handle created with NMPC_GUARD=<KiB> in the environment
+ * places each of its allocations between two bands of that size filled with a pattern; this call synchronises the device and
+ * returns the number of band bytes that no longer hold it (0 = no store outside any buffer within that distance; nmpc_last_error
+ * names the first damaged buffer), -1 when the handle was created without NMPC_GUARD.  A store past a buffer that stays inside
+ * mapped memory does not fault - this is how it shows (tests/test_gpu_parity.py runs the 3-4 integrator-step regression under it). */
+long long nmpc_debug_guard_check(nmpc_solver *s);
+
 /* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */
 const char *nmpc_version(void);
 

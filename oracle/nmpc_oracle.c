@@ -26,6 +26,43 @@
 #define NY ORC_NY
 
 /* ------------------------------------------------------------------------------------ */
+/* Workspace memory.  A solve allocates ~10 N small arrays; done with malloc / free inside an OpenMP loop over instances the
+ * allocator's locks serialise the threads (round 3: 2.6x on 256 cores).  orc_solve_batch_ex gives every thread ONE arena that
+ * it resets per instance: an allocation is a pointer bump, a free is nothing, no lock is taken inside a solve.  Outside the
+ * batch loop (single solves, the tests' direct calls) no arena is installed and these are malloc / free.  Not a change of the
+ * arithmetic: only where the same arrays live.  (The sanitizer build keeps the heap, so ASan still sees every array.)          */
+typedef struct { char *base; size_t cap, off, need; } orc_arena;
+#if defined(__SANITIZE_ADDRESS__)
+#define ORC_USE_ARENA 0
+#else
+#define ORC_USE_ARENA 1
+#endif
+#define ORC_ARENA_MAX ((size_t)64 << 20)
+static _Thread_local orc_arena *t_arena = NULL;
+static void *orc_malloc(size_t n)
+{
+    orc_arena *a = t_arena;
+    if (a) {
+        const size_t m = (n + 63) & ~(size_t)63;
+        a->need += m;
+        if (a->off + m <= a->cap) { void *p = a->base + a->off; a->off += m; return p; }
+    }
+    return malloc(n ? n : 1);
+}
+static void *orc_calloc(size_t k, size_t sz)
+{
+    void *p = orc_malloc(k * sz);
+    if (p) memset(p, 0, k * sz);
+    return p;
+}
+static void orc_free(void *p)
+{
+    const orc_arena *a = t_arena;
+    if (a && (char *)p >= a->base && (char *)p < a->base + a->cap) return;   /* arena memory: released by the reset */
+    free(p);
+}
+
+/* ------------------------------------------------------------------------------------ */
 /* defaults: reference config/params.yaml:1-33 and controller.py:98-110                  */
 void orc_default_config(orc_config *c)
 {
@@ -305,17 +342,17 @@ typedef struct {
     double *QN, *qN;        /* terminal nx*nx, nx */
 } ocpqp;
 
-static double *dalloc(size_t n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+static double *dalloc(size_t n) { return (double *)orc_calloc(n ? n : 1, sizeof(double)); }
 
 static void ocpqp_alloc(ocpqp *p, int N, const int *nu)
 {
     p->N = N;
-    p->nu = (int *)malloc(sizeof(int) * (size_t)N);
-    p->A = (double **)malloc(sizeof(double *) * N); p->B = (double **)malloc(sizeof(double *) * N);
-    p->b = (double **)malloc(sizeof(double *) * N); p->Q = (double **)malloc(sizeof(double *) * N);
-    p->R = (double **)malloc(sizeof(double *) * N); p->S = (double **)malloc(sizeof(double *) * N);
-    p->q = (double **)malloc(sizeof(double *) * N); p->r = (double **)malloc(sizeof(double *) * N);
-    p->lo = (double **)malloc(sizeof(double *) * N); p->hi = (double **)malloc(sizeof(double *) * N);
+    p->nu = (int *)orc_malloc(sizeof(int) * (size_t)N);
+    p->A = (double **)orc_malloc(sizeof(double *) * N); p->B = (double **)orc_malloc(sizeof(double *) * N);
+    p->b = (double **)orc_malloc(sizeof(double *) * N); p->Q = (double **)orc_malloc(sizeof(double *) * N);
+    p->R = (double **)orc_malloc(sizeof(double *) * N); p->S = (double **)orc_malloc(sizeof(double *) * N);
+    p->q = (double **)orc_malloc(sizeof(double *) * N); p->r = (double **)orc_malloc(sizeof(double *) * N);
+    p->lo = (double **)orc_malloc(sizeof(double *) * N); p->hi = (double **)orc_malloc(sizeof(double *) * N);
     for (int k = 0; k < N; k++) {
         const int m = nu[k];
         p->nu[k] = m;
@@ -330,11 +367,11 @@ static void ocpqp_alloc(ocpqp *p, int N, const int *nu)
 static void ocpqp_free(ocpqp *p)
 {
     for (int k = 0; k < p->N; k++) {
-        free(p->A[k]); free(p->B[k]); free(p->b[k]); free(p->Q[k]); free(p->R[k]); free(p->S[k]);
-        free(p->q[k]); free(p->r[k]); free(p->lo[k]); free(p->hi[k]);
+        orc_free(p->A[k]); orc_free(p->B[k]); orc_free(p->b[k]); orc_free(p->Q[k]); orc_free(p->R[k]); orc_free(p->S[k]);
+        orc_free(p->q[k]); orc_free(p->r[k]); orc_free(p->lo[k]); orc_free(p->hi[k]);
     }
-    free(p->A); free(p->B); free(p->b); free(p->Q); free(p->R); free(p->S);
-    free(p->q); free(p->r); free(p->lo); free(p->hi); free(p->nu); free(p->QN); free(p->qN);
+    orc_free(p->A); orc_free(p->B); orc_free(p->b); orc_free(p->Q); orc_free(p->R); orc_free(p->S);
+    orc_free(p->q); orc_free(p->r); orc_free(p->lo); orc_free(p->hi); orc_free(p->nu); orc_free(p->QN); orc_free(p->qN);
 }
 
 /* in-place lower Cholesky of an m*m row-major SPD matrix; returns 0 ok, 1 not SPD */
@@ -447,7 +484,7 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
                     for (int l = 0; l < NX; l++) s += A[l * NX + i] * PA[l * NX + j];
                     Hxx[i * NX + j] = s;
                 }
-            if (chol_lower(L, m)) { free(PB); free(gu); return 1; }
+            if (chol_lower(L, m)) { orc_free(PB); orc_free(gu); return 1; }
             trsm_lower(L, m, M, NX);
             /* P_k = Hxx - M'M, symmetrised */
             for (int i = 0; i < NX; i++)
@@ -478,8 +515,8 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
             pv[i] = s;
         }
         if (factor && f->P) { memcpy(f->P[k], P, sizeof(P)); memcpy(f->p[k], pv, sizeof(pv)); }
-        free(PB);
-        free(gu);
+        orc_free(PB);
+        orc_free(gu);
     }
     return 0;
 }
@@ -528,26 +565,26 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
      * call's first pass sets it); a pass whose g exceeds growth_max * *gbase ends the attempt unaccepted, *untrusted = 1 */
     const int N = p->N;
     ocpqp m = *p;
-    m.B = (double **)malloc(sizeof(double *) * N); m.b = (double **)malloc(sizeof(double *) * N);
-    m.R = (double **)malloc(sizeof(double *) * N); m.S = (double **)malloc(sizeof(double *) * N);
-    m.q = (double **)malloc(sizeof(double *) * N); m.r = (double **)malloc(sizeof(double *) * N);
-    double **zero = (double **)malloc(sizeof(double *) * N), **uh = (double **)malloc(sizeof(double *) * N);
-    int **pin = (int **)malloc(sizeof(int *) * N), **newpin = (int **)malloc(sizeof(int *) * N);
-    double **gsave = (double **)malloc(sizeof(double *) * N);
+    m.B = (double **)orc_malloc(sizeof(double *) * N); m.b = (double **)orc_malloc(sizeof(double *) * N);
+    m.R = (double **)orc_malloc(sizeof(double *) * N); m.S = (double **)orc_malloc(sizeof(double *) * N);
+    m.q = (double **)orc_malloc(sizeof(double *) * N); m.r = (double **)orc_malloc(sizeof(double *) * N);
+    double **zero = (double **)orc_malloc(sizeof(double *) * N), **uh = (double **)orc_malloc(sizeof(double *) * N);
+    int **pin = (int **)orc_malloc(sizeof(int *) * N), **newpin = (int **)orc_malloc(sizeof(int *) * N);
+    double **gsave = (double **)orc_malloc(sizeof(double *) * N);
     double *xh = dalloc((size_t)(N + 1) * NX);
     /* the cost-to-go of every pass is kept: the multiplier of a pinned input is formed with the costate P_{k+1} x_{k+1} + p_{k+1}.
      * (The adjoint recursion pi_k = Q x + q + A'pi_{k+1} gives the same number in exact arithmetic but amplifies rounding by
      * rho(A) per stage: on a violently unstable plant - rho = 2, N = 120 - it accepted active sets whose multipliers, solved in
      * 60 digits, had the wrong sign by 8e-2, where the tile kernels' P-based check went on to the right set.)                  */
     ricc_fact fp = *f;
-    fp.P = (double **)malloc(sizeof(double *) * (size_t)(N + 1)); fp.p = (double **)malloc(sizeof(double *) * (size_t)(N + 1));
+    fp.P = (double **)orc_malloc(sizeof(double *) * (size_t)(N + 1)); fp.p = (double **)orc_malloc(sizeof(double *) * (size_t)(N + 1));
     for (int k = 0; k <= N; k++) { fp.P[k] = dalloc(NX * NX); fp.p[k] = dalloc(NX); }
     for (int k = 0; k < N; k++) {
         const int nu = p->nu[k];
         m.B[k] = dalloc((size_t)NX * nu); m.b[k] = dalloc(NX); m.R[k] = dalloc((size_t)nu * nu);
         m.S[k] = dalloc((size_t)nu * NX); m.q[k] = dalloc(NX); m.r[k] = dalloc(nu);
-        zero[k] = dalloc(nu); uh[k] = dalloc(nu); pin[k] = (int *)calloc((size_t)nu, sizeof(int));
-        newpin[k] = (int *)calloc((size_t)nu, sizeof(int)); gsave[k] = dalloc(nu);
+        zero[k] = dalloc(nu); uh[k] = dalloc(nu); pin[k] = (int *)orc_calloc((size_t)nu, sizeof(int));
+        newpin[k] = (int *)orc_calloc((size_t)nu, sizeof(int)); gsave[k] = dalloc(nu);
         memcpy(m.B[k], p->B[k], sizeof(double) * NX * nu); memcpy(m.b[k], p->b[k], sizeof(double) * NX);
         memcpy(m.R[k], p->R[k], sizeof(double) * nu * nu); memcpy(m.S[k], p->S[k], sizeof(double) * nu * NX);
         memcpy(m.q[k], p->q[k], sizeof(double) * NX); memcpy(m.r[k], p->r[k], sizeof(double) * nu);
@@ -676,13 +713,13 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         memcpy(x, xh, sizeof(double) * (size_t)(N + 1) * NX);
     }
     for (int k = 0; k < N; k++) {
-        free(m.B[k]); free(m.b[k]); free(m.R[k]); free(m.S[k]); free(m.q[k]); free(m.r[k]);
-        free(zero[k]); free(uh[k]); free(pin[k]); free(newpin[k]); free(gsave[k]);
+        orc_free(m.B[k]); orc_free(m.b[k]); orc_free(m.R[k]); orc_free(m.S[k]); orc_free(m.q[k]); orc_free(m.r[k]);
+        orc_free(zero[k]); orc_free(uh[k]); orc_free(pin[k]); orc_free(newpin[k]); orc_free(gsave[k]);
     }
-    for (int k = 0; k <= N; k++) { free(fp.P[k]); free(fp.p[k]); }
-    free(fp.P); free(fp.p);
-    free(newpin); free(gsave);
-    free(m.B); free(m.b); free(m.R); free(m.S); free(m.q); free(m.r); free(zero); free(uh); free(pin); free(xh);
+    for (int k = 0; k <= N; k++) { orc_free(fp.P[k]); orc_free(fp.p[k]); }
+    orc_free(fp.P); orc_free(fp.p);
+    orc_free(newpin); orc_free(gsave);
+    orc_free(m.B); orc_free(m.b); orc_free(m.R); orc_free(m.S); orc_free(m.q); orc_free(m.r); orc_free(zero); orc_free(uh); orc_free(pin); orc_free(xh);
     return ok;
 }
 
@@ -715,14 +752,14 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     const int N = p->N;
     int nc = 0, status = 0, it = 0;
     ricc_fact f;
-    f.L = (double **)malloc(sizeof(double *) * N);
-    f.M = (double **)malloc(sizeof(double *) * N);
-    f.m = (double **)malloc(sizeof(double *) * N);
+    f.L = (double **)orc_malloc(sizeof(double *) * N);
+    f.M = (double **)orc_malloc(sizeof(double *) * N);
+    f.m = (double **)orc_malloc(sizeof(double *) * N);
     f.P = NULL; f.p = NULL;
-    double **ll = (double **)malloc(sizeof(double *) * N), **lu = (double **)malloc(sizeof(double *) * N);
-    double **sig = (double **)malloc(sizeof(double *) * N), **rh = (double **)malloc(sizeof(double *) * N);
-    double **ua = (double **)malloc(sizeof(double *) * N), **du = (double **)malloc(sizeof(double *) * N);
-    double **dla = (double **)malloc(sizeof(double *) * N), **dua = (double **)malloc(sizeof(double *) * N);
+    double **ll = (double **)orc_malloc(sizeof(double *) * N), **lu = (double **)orc_malloc(sizeof(double *) * N);
+    double **sig = (double **)orc_malloc(sizeof(double *) * N), **rh = (double **)orc_malloc(sizeof(double *) * N);
+    double **ua = (double **)orc_malloc(sizeof(double *) * N), **du = (double **)orc_malloc(sizeof(double *) * N);
+    double **dla = (double **)orc_malloc(sizeof(double *) * N), **dua = (double **)orc_malloc(sizeof(double *) * N);
     double *xh = dalloc((size_t)(N + 1) * NX);
     for (int k = 0; k < N; k++) {
         const int m = p->nu[k];
@@ -927,11 +964,11 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         st->growth = growth; st->step_last = step_last; st->untrusted = untrusted;
     }
     for (int k = 0; k < N; k++) {
-        free(f.L[k]); free(f.M[k]); free(f.m[k]); free(ll[k]); free(lu[k]); free(sig[k]);
-        free(rh[k]); free(ua[k]); free(du[k]); free(dla[k]); free(dua[k]);
+        orc_free(f.L[k]); orc_free(f.M[k]); orc_free(f.m[k]); orc_free(ll[k]); orc_free(lu[k]); orc_free(sig[k]);
+        orc_free(rh[k]); orc_free(ua[k]); orc_free(du[k]); orc_free(dla[k]); orc_free(dua[k]);
     }
-    free(f.L); free(f.M); free(f.m); free(ll); free(lu); free(sig); free(rh); free(ua);
-    free(du); free(dla); free(dua); free(xh);
+    orc_free(f.L); orc_free(f.M); orc_free(f.m); orc_free(ll); orc_free(lu); orc_free(sig); orc_free(rh); orc_free(ua);
+    orc_free(du); orc_free(dla); orc_free(dua); orc_free(xh);
     return status;
 }
 
@@ -951,17 +988,17 @@ int orc_qp_solve(const orc_config *c, const double *dx0,
 {
     const int N = c->N;
     int N2 = (c->qp_cond_N > 0 && c->qp_cond_N < N) ? c->qp_cond_N : N;
-    int *bs = (int *)malloc(sizeof(int) * (size_t)N2);
-    int *nu2 = (int *)malloc(sizeof(int) * (size_t)N2);
+    int *bs = (int *)orc_malloc(sizeof(int) * (size_t)N2);
+    int *nu2 = (int *)orc_malloc(sizeof(int) * (size_t)N2);
     cond_block_sizes(N, N2, bs);
     for (int i = 0; i < N2; i++) nu2[i] = NU * bs[i];
     ocpqp p;
     ocpqp_alloc(&p, N2, nu2);
     /* per block: Phi_j (nx*nx), Gam_j (nx*nub), c_j (nx) for j = 0..bs (U8) */
     int k0 = 0;
-    double **Phi_all = (double **)malloc(sizeof(double *) * N2);
-    double **Gam_all = (double **)malloc(sizeof(double *) * N2);
-    double **c_all = (double **)malloc(sizeof(double *) * N2);
+    double **Phi_all = (double **)orc_malloc(sizeof(double *) * N2);
+    double **Gam_all = (double **)orc_malloc(sizeof(double *) * N2);
+    double **c_all = (double **)orc_malloc(sizeof(double *) * N2);
     for (int ib = 0; ib < N2; ib++) {
         const int nb = bs[ib], m = nu2[ib];
         double *Phi = dalloc((size_t)(nb + 1) * NX * NX);
@@ -1038,7 +1075,7 @@ int orc_qp_solve(const orc_config *c, const double *dx0,
         p.QN[i * NX + i] = Qd[(size_t)N * NX + i];
         p.qN[i] = q[(size_t)N * NX + i];
     }
-    double **u2 = (double **)malloc(sizeof(double *) * N2);
+    double **u2 = (double **)orc_malloc(sizeof(double *) * N2);
     for (int ib = 0; ib < N2; ib++) u2[ib] = dalloc(nu2[ib]);
     double *x2 = dalloc((size_t)(N2 + 1) * NX);
     const int status = ocpqp_ipm(c, &p, dx0, u2, x2, st);
@@ -1061,9 +1098,9 @@ int orc_qp_solve(const orc_config *c, const double *dx0,
     }
     memcpy(dx + (size_t)N * NX, x2 + (size_t)N2 * NX, sizeof(double) * NX);
     for (int ib = 0; ib < N2; ib++) {
-        free(u2[ib]); free(Phi_all[ib]); free(Gam_all[ib]); free(c_all[ib]);
+        orc_free(u2[ib]); orc_free(Phi_all[ib]); orc_free(Gam_all[ib]); orc_free(c_all[ib]);
     }
-    free(u2); free(x2); free(Phi_all); free(Gam_all); free(c_all); free(bs); free(nu2);
+    orc_free(u2); orc_free(x2); orc_free(Phi_all); orc_free(Gam_all); orc_free(c_all); orc_free(bs); orc_free(nu2);
     ocpqp_free(&p);
     return status;
 }
@@ -1100,8 +1137,8 @@ int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
         for (int i = 0; i < N * NU; i++) utraj[i] += du[i];
     }
     if (st) *st = local;
-    free(A); free(B); free(b); free(q); free(r); free(lo); free(hi); free(Qd); free(Rd);
-    free(dx); free(du);
+    orc_free(A); orc_free(B); orc_free(b); orc_free(q); orc_free(r); orc_free(lo); orc_free(hi); orc_free(Qd); orc_free(Rd);
+    orc_free(dx); orc_free(du);
     return status;
 }
 
@@ -1126,10 +1163,21 @@ int orc_solve_batch_ex(const orc_config *c, int Bn, const double *x0, const doub
 #else
     (void)nthreads;
 #endif
-#pragma omp parallel for schedule(dynamic, 16)
+#pragma omp parallel
+    {
+        /* one arena per thread, reset per instance, grown between instances to what the largest one asked for */
+        orc_arena ar = {NULL, 0, 0, 0};
+        if (ORC_USE_ARENA) {
+            ar.cap = (size_t)1 << 20;
+            ar.base = (char *)malloc(ar.cap);
+            if (!ar.base) ar.cap = 0;
+            t_arena = &ar;
+        }
+#pragma omp for schedule(static)
     for (int ib = 0; ib < Bn; ib++) {
-        double *xt = (double *)malloc(sizeof(double) * (size_t)(N + 1) * NX);
-        double *ut = (double *)malloc(sizeof(double) * (size_t)N * NU);
+        ar.off = 0; ar.need = 0;
+        double *xt = (double *)orc_malloc(sizeof(double) * (size_t)(N + 1) * NX);
+        double *ut = (double *)orc_malloc(sizeof(double) * (size_t)N * NU);
         const double *x0i = x0 + (size_t)ib * NX;
         if (x_init && u_init) {
             memcpy(xt, x_init + (size_t)ib * (N + 1) * NX, sizeof(double) * (size_t)(N + 1) * NX);
@@ -1154,8 +1202,18 @@ int orc_solve_batch_ex(const orc_config *c, int Bn, const double *x0, const doub
         }
         if (x_out) memcpy(x_out + (size_t)ib * (N + 1) * NX, xt, sizeof(double) * (size_t)(N + 1) * NX);
         if (u_out) memcpy(u_out + (size_t)ib * N * NU, ut, sizeof(double) * (size_t)N * NU);
-        free(xt);
-        free(ut);
+        orc_free(xt);
+        orc_free(ut);
+        if (ORC_USE_ARENA && ar.need > ar.cap && ar.cap < ORC_ARENA_MAX) {             /* (some allocations of this instance fell back to the heap) */
+            free(ar.base);
+            ar.cap = ar.need + ar.need / 2;
+            if (ar.cap > ORC_ARENA_MAX) ar.cap = ORC_ARENA_MAX;   /* (beyond that the heap serves the rest: long horizons, condensed blocks) */
+            ar.base = (char *)malloc(ar.cap);
+            if (!ar.base) ar.cap = 0;
+        }
+    }
+        t_arena = NULL;
+        free(ar.base);
     }
     return 0;
 }

@@ -1,7 +1,7 @@
 // nmpc_as_launch.hpp -- host-side hand-over between the C ABI (nmpc_capi.hip) and the two translation units that hold the kernels of
 // nmpc_team_as.hpp: nmpc_as.hip (k_team_as built with -mllvm -amdgpu-mfma-vgpr-form: MFMA results in the vector registers the
-// following VALU reads, +9 % on that kernel) and nmpc_qp.hip (everything else, default code generation - the flag miscompiles
-// other instantiations, see nmpc_qp.hip).
+// following VALU reads, +7 % on that kernel) and nmpc_qp.hip (everything else, default code generation - the flag is an internal
+// option, validated for that one kernel only: see nmpc_qp.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>

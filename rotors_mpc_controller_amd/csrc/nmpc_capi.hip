@@ -120,6 +120,7 @@ struct nmpc_solver {
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
+    int as_v256 = 0;                 // NMPC_AS_BUILD=v256: the 256-register build with the LDS stage cache (nmpc_qp.hip, OCC = 3)
     int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
@@ -137,6 +138,7 @@ struct nmpc_solver {
     uint64_t ws_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start | after prepare | after the (first) solve kernel | after the work-list launch
     bool timed_split = false, last_split = false;
+    bool last_shared = false;        // the last solve linearised ONE interval (shared cold start): tAB then holds stage-0 tiles only
     int last_B = 0;
     bool timed = false, timed_fused = false, solved = false;
     bool timing = true;   // nmpc_set_timing: HIP events around the kernels of every solve
@@ -163,6 +165,11 @@ struct nmpc_solver {
     int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
     int team_mfma = 1;  // FP64 factor sweep in tile form on v_mfma_f64_4x4x4; NMPC_TEAM_MFMA=0 keeps the VALU form
 
+    // canaries around every device allocation of the handle (NMPC_GUARD=<KiB>, off by default): nmpc_debug_guard_check
+    size_t guard = 0;
+    struct GuardRec { char *base; size_t n; };
+    std::vector<GuardRec> guards;
+
     int fail(int code, const char *fmt, ...)
     {
         char buf[512];
@@ -174,6 +181,36 @@ struct nmpc_solver {
         return code;
     }
 };
+
+
+// Device allocations of a handle.  With NMPC_GUARD=<KiB> in the environment at create, every buffer sits between two canary
+// bands of that size filled with 0xA5; nmpc_debug_guard_check() reports any byte of a band that a kernel (or a copy) has changed -
+// a store outside a buffer that stays inside mapped memory does not fault, it corrupts a neighbour, and this is how it shows.
+static hipError_t gmalloc(nmpc_solver *s, void **p, size_t n)
+{
+    if (!s->guard) return hipMalloc(p, n);
+    char *b = nullptr;
+    hipError_t e = hipMalloc((void **)&b, n + 2 * s->guard);
+    if (e != hipSuccess) return e;
+    e = hipMemset(b, 0xA5, s->guard);
+    if (e == hipSuccess) e = hipMemset(b + s->guard + n, 0xA5, s->guard);
+    if (e != hipSuccess) { (void)hipFree(b); return e; }
+    s->guards.push_back({b, n});
+    *p = b + s->guard;
+    return hipSuccess;
+}
+static hipError_t gfree(nmpc_solver *s, void *p)
+{
+    if (s->guard) {
+        for (size_t i = 0; i < s->guards.size(); i++)
+            if (s->guards[i].base + s->guard == (char *)p) {
+                char *b = s->guards[i].base;
+                s->guards.erase(s->guards.begin() + i);
+                return hipFree(b);
+            }
+    }
+    return hipFree(p);
+}
 
 #define HIP_TRY(s, call)                                                                      \
     do {                                                                                      \
@@ -269,21 +306,21 @@ static int alloc_ws(nmpc_solver *s)
         {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)},
         {(void **)&s->d_wl, (Bp + 2) * sizeof(int)}, {(void **)&s->d_gbase, (Bp + 1) * sizeof(double)}};
     for (auto &x : a) {
-        HIP_TRY(s, hipMalloc(x.p, x.n));
+        HIP_TRY(s, gmalloc(s, x.p, x.n));
         s->ws_bytes += x.n;
     }
     HIP_TRY(s, hipMemset(s->d_wl, 0, (Bp + 2) * sizeof(int)));
     {
         Consts<double> cd;
         fill_consts(s->cfg, cd);
-        HIP_TRY(s, hipMalloc(&s->d_consts, sizeof(cd)));
+        HIP_TRY(s, gmalloc(s, &s->d_consts, sizeof(cd)));
         HIP_TRY(s, hipMemcpy(s->d_consts, &cd, sizeof(cd), hipMemcpyHostToDevice));
     }
     if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
         CondWork<double> cw;
         const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
         const size_t n = (size_t)cond_layout(cw, s->cfg.N, N2) * Bp * e;
-        HIP_TRY(s, hipMalloc(&s->cond, n));
+        HIP_TRY(s, gmalloc(s, &s->cond, n));
         s->ws_bytes += n;
     }
     return 0;
@@ -304,7 +341,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
                         cfg->qp_polish_mu >= cfg->qp_mu0 &&
                         cfg->sim_num_steps <= AS_MAX_STEPS && !(cfg->qp_mu0 <= cfg->qp_tol_comp);
         if (!ok) return bad("nmpc_create: NMPC_DTYPE_F32IO runs on the default path only (team mapping, qp_polish = 1 with its first "
-                            "attempt before any interior-point iteration, sim_num_steps <= 2, no condensing)");
+                            "attempt before any interior-point iteration, sim_num_steps <= 4, no condensing)");
     }
     if (cfg->max_batch < 1) return bad("nmpc_create: max_batch must be >= 1");
     if (!(cfg->mass > 0) || !(cfg->inertia[0] > 0) || !(cfg->inertia[1] > 0) || !(cfg->inertia[2] > 0))
@@ -350,11 +387,16 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         const int v = std::atoi(e);
         if (v == 1 || v == 2) s->team_occ = v;
     }
+    if (const char *e = std::getenv("NMPC_GUARD")) s->guard = (size_t)std::max(0, std::atoi(e)) * 1024;
     if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_AS_BUILD")) {
+        s->as_v256 = std::strcmp(e, "v256") == 0;
+        if (std::strcmp(e, "default") == 0) s->as_noflag = 1;
+    }
     if (const char *e = std::getenv("NMPC_TEAM_LSTG")) s->team_lstg = std::atoi(e);
     if (const char *e = std::getenv("NMPC_BLOCK_TAIL")) s->block_tail = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_BLOCK_J")) s->block_J = std::atoi(e);
@@ -386,15 +428,15 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
             const int M = (g.N + J - 1) / J;
             J = (g.N + M - 1) / M;
             const size_t Bw = (size_t)s->Bp + 1;
-            bool ok = hipMalloc((void **)&s->d_ts, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->d_binfo, Bw * J * 2 * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->tail_agg, Bw * J * 3 * BLK_MAT * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
-                      hipMalloc((void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
-                      hipMalloc((void **)&s->tail_gbuf, Bw * J * BLK_GB * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->tail_xb, Bw * J * 16 * sizeof(double)) == hipSuccess &&
-                      hipMalloc((void **)&s->tail_frec, Bw * J * FR_ROWS * sizeof(double)) == hipSuccess;
+            bool ok = gmalloc(s, (void **)&s->d_ts, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->d_binfo, Bw * J * 2 * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->tail_agg, Bw * J * 3 * BLK_MAT * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->tail_gbuf, Bw * J * BLK_GB * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->tail_xb, Bw * J * 16 * sizeof(double)) == hipSuccess &&
+                      gmalloc(s, (void **)&s->tail_frec, Bw * J * FR_ROWS * sizeof(double)) == hipSuccess;
             ok = ok && hipMemset(s->d_wl2, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_wl3, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_ts, 0, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
@@ -409,7 +451,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         }
     }
 #ifdef NMPC_PROFILE
-    if (hipMalloc((void **)&s->d_prof, (size_t)8 * s->Bp * sizeof(long long)) != hipSuccess) s->d_prof = nullptr;
+    if (gmalloc(s, (void **)&s->d_prof, (size_t)8 * s->Bp * sizeof(long long)) != hipSuccess) s->d_prof = nullptr;
 #endif
     for (auto &e : s->ev)
         if (hipEventCreate(&e) != hipSuccess) { g_create_error = "hipEventCreate failed"; nmpc_destroy(s); return nullptr; }
@@ -430,15 +472,15 @@ void nmpc_destroy(nmpc_solver *s)
     void *ptrs[] = {s->d_gbase, s->d_consts, s->d_wl, s->d_npol, s->cond, s->tAB, s->tP, s->d_prof, s->AB, s->bv, s->qr, s->xl, s->ul, s->LM, s->iv, s->d_iters, s->d_status, s->s_x0,
                     s->s_yref, s->s_yref_e, s->s_xi, s->s_ui, s->s_u0, s->s_xo, s->s_uo};
     for (void *p : ptrs)
-        if (p) (void)hipFree(p);
+        if (p) (void)gfree(s, p);
     for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac, (void *)s->d_ts, (void *)s->d_binfo,
                     (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3, (void *)s->tail_gbuf, (void *)s->tail_xb,
                     (void *)s->tail_frec})
-        if (p) (void)hipFree(p);
+        if (p) (void)gfree(s, p);
     for (auto &e : s->blk_ev)
         if (e) (void)hipEventDestroy(e);
-    if (s->d_in) (void)hipFree(s->d_in);
-    if (s->d_out) (void)hipFree(s->d_out);
+    if (s->d_in) (void)gfree(s, s->d_in);
+    if (s->d_out) (void)gfree(s, s->d_out);
     if (s->h_in) (void)hipHostFree(s->h_in);
     if (s->h_out) (void)hipHostFree(s->h_out);
     if (s->pack_stream) (void)hipStreamDestroy(s->pack_stream);
@@ -448,6 +490,31 @@ void nmpc_destroy(nmpc_solver *s)
 }
 
 const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
+
+// Diagnostics (include/rotors_nmpc.h): bytes of the canary bands around the handle's device buffers that no longer hold the fill
+// pattern; -1 when the handle was created without NMPC_GUARD.  nmpc_last_error() names the first damaged buffer.
+long long nmpc_debug_guard_check(nmpc_solver *s)
+{
+    if (!s) return NMPC_EARG;
+    if (!s->guard) return -1;
+    if (hipSetDevice(s->cfg.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return s->fail(NMPC_EHIP, "guard_check: device synchronisation failed");
+    std::vector<unsigned char> h(2 * s->guard);
+    long long bad = 0;
+    for (size_t i = 0; i < s->guards.size(); i++) {
+        const auto &g = s->guards[i];
+        if (hipMemcpy(h.data(), g.base, s->guard, hipMemcpyDeviceToHost) != hipSuccess ||
+            hipMemcpy(h.data() + s->guard, g.base + s->guard + g.n, s->guard, hipMemcpyDeviceToHost) != hipSuccess)
+            return s->fail(NMPC_EHIP, "guard_check: copy failed");
+        long long b = 0, first = -1;
+        for (size_t k = 0; k < h.size(); k++)
+            if (h[k] != 0xA5) { b++; if (first < 0) first = (long long)k; }
+        if (b && !bad)
+            s->fail(0, "guard_check: buffer %zu (%zu bytes): %lld damaged canary bytes, first %s the buffer at distance %lld", i, g.n, b,
+                    first < (long long)s->guard ? "below" : "above", first < (long long)s->guard ? (long long)s->guard - first : first - (long long)s->guard);
+        bad += b;
+    }
+    return bad;
+}
 
 }  // extern "C"
 
@@ -509,12 +576,16 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const bool tail = s->team_qp && s->tail_J > 0;
     const int cap = tail ? std::max(1, std::min(s->tail_cap > 0 ? s->tail_cap : s->cfg.qp_polish_passes, s->cfg.qp_polish_passes)) : 0;
     if (tail) {
+        // the tail's lists are reset by its last launches; a solve that returned early with an error leaves counts behind, and the next
+        // one would append past list[Bp]: the three headers (count | done) start every solve at zero
+        for (int *h : {s->d_wl, s->d_wl2, s->d_wl3}) HIP_TRY(s, hipMemsetAsync(h, 0, 2 * sizeof(int), st));
         HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
         al.tail.cap = cap < s->cfg.qp_polish_passes ? cap : 0;
         al.tail.ts = s->d_ts;
     }
     // k_team_as: the flag build (nmpc_as.hip) for what it is validated on, the default-codegen build (nmpc_qp.hip) otherwise
-    if (s->cfg.sim_num_steps <= 2 && !s->as_noflag) HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
+    if (s->as_v256 && al.shared && al.occ == 1) { al.occ = 3; HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out)); al.occ = 1; }
+    else if (s->cfg.sim_num_steps <= 2 && !s->as_noflag) HIP_TRY(s, (hipError_t)launch_team_as(al, in, out));
     else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
     if (tail) {
@@ -592,6 +663,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     HIP_TRY(s, hipGetLastError());
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
     s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
+    s->last_shared = c.shared != 0;
     return 0;
 }
 
@@ -709,6 +781,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                 HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
                 if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
                 s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
+                s->last_shared = c.shared != 0;
                 return 0;
             }
         }
@@ -736,6 +809,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     s->timed_fused = fused != 0;
     s->timed_split = false;
     s->last_split = false;
+    s->last_shared = c.shared != 0;
     return 0;
 }
 
@@ -764,16 +838,16 @@ static int ensure_staging(nmpc_solver *s, size_t B)
     s->staged_batch = 0;      // a failed grow below must force a fresh allocation on the next call
     void **ps[] = {&s->s_x0, &s->s_yref, &s->s_yref_e, &s->s_xi, &s->s_ui, &s->s_u0, &s->s_xo, &s->s_uo};
     for (void **p : ps)
-        if (*p) { (void)hipFree(*p); *p = nullptr; }
+        if (*p) { (void)gfree(s, *p); *p = nullptr; }
     const size_t N = (size_t)s->cfg.N, e = s->esz;
-    HIP_TRY(s, hipMalloc(&s->s_x0, B * NX * e));
-    HIP_TRY(s, hipMalloc(&s->s_yref, B * N * NY * e));
-    HIP_TRY(s, hipMalloc(&s->s_yref_e, B * NX * e));
-    HIP_TRY(s, hipMalloc(&s->s_xi, B * (N + 1) * NX * e));
-    HIP_TRY(s, hipMalloc(&s->s_ui, B * N * NU * e));
-    HIP_TRY(s, hipMalloc(&s->s_u0, B * NU * e));
-    HIP_TRY(s, hipMalloc(&s->s_xo, B * (N + 1) * NX * e));
-    HIP_TRY(s, hipMalloc(&s->s_uo, B * N * NU * e));
+    HIP_TRY(s, gmalloc(s, &s->s_x0, B * NX * e));
+    HIP_TRY(s, gmalloc(s, &s->s_yref, B * N * NY * e));
+    HIP_TRY(s, gmalloc(s, &s->s_yref_e, B * NX * e));
+    HIP_TRY(s, gmalloc(s, &s->s_xi, B * (N + 1) * NX * e));
+    HIP_TRY(s, gmalloc(s, &s->s_ui, B * N * NU * e));
+    HIP_TRY(s, gmalloc(s, &s->s_u0, B * NU * e));
+    HIP_TRY(s, gmalloc(s, &s->s_xo, B * (N + 1) * NX * e));
+    HIP_TRY(s, gmalloc(s, &s->s_uo, B * N * NU * e));
     s->staged_batch = B;
     return 0;
 }
@@ -830,11 +904,11 @@ static int solve_packed(nmpc_solver *s, int B, const double *x0, const double *y
         hipError_t pe = hipStreamCreateWithFlags(&s->pack_stream, hipStreamNonBlocking);
         if (pe == hipSuccess) pe = hipHostMalloc(&s->h_in, s->pack_in_bytes, hipHostMallocDefault);
         if (pe == hipSuccess) pe = hipHostMalloc(&s->h_out, s->pack_out_bytes, hipHostMallocDefault);
-        if (pe == hipSuccess) pe = hipMalloc(&s->d_in, s->pack_in_bytes);
-        if (pe == hipSuccess) pe = hipMalloc(&s->d_out, s->pack_out_bytes);
+        if (pe == hipSuccess) pe = gmalloc(s, &s->d_in, s->pack_in_bytes);
+        if (pe == hipSuccess) pe = gmalloc(s, &s->d_out, s->pack_out_bytes);
         if (pe != hipSuccess) {
-            if (s->d_out) (void)hipFree(s->d_out);
-            if (s->d_in) (void)hipFree(s->d_in);
+            if (s->d_out) (void)gfree(s, s->d_out);
+            if (s->d_in) (void)gfree(s, s->d_in);
             if (s->h_out) (void)hipHostFree(s->h_out);
             if (s->h_in) (void)hipHostFree(s->h_in);
             if (s->pack_stream) (void)hipStreamDestroy(s->pack_stream);
@@ -1126,6 +1200,10 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
     if (!s->solved || s->last_B < B) return s->fail(NMPC_EARG, "block_factor: no solve of >= %d instances on this handle yet", B);
     if (x_init == nullptr && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START))
         return s->fail(NMPC_EARG, "block_factor: needs the per-stage linearisation (a warm start, or NMPC_FLAG_SHARE_COLD_START off)");
+    // ... of the LAST solve: the sweeps read the stage tiles that solve left in the workspace, whatever this call's arguments say
+    if (s->last_shared)
+        return s->fail(NMPC_EARG, "block_factor: the last solve on this handle shared one cold-start linearisation - only stage-0 tiles exist; "
+                                  "solve with a warm start (or NMPC_FLAG_SHARE_COLD_START off) first");
     if (s->cfg.sim_num_steps > AS_MAX_STEPS) return s->fail(NMPC_EARG, "block_factor: sim_num_steps > %d is not built", AS_MAX_STEPS);
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     hipStream_t st = (hipStream_t)hip_stream;
@@ -1134,15 +1212,15 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
     const size_t Bw = (size_t)s->Bp + 1;
     if (Jeff > s->blk_J || !s->blk_fac) {
         for (double **p : {&s->blk_agg, &s->blk_bnd, &s->blk_chk, &s->blk_fac})
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
+            if (*p) { (void)gfree(s, *p); *p = nullptr; }
         s->blk_J = 0;
-        HIP_TRY(s, hipMalloc((void **)&s->blk_agg, Bw * Jeff * 3 * BLK_MAT * sizeof(double)));
-        HIP_TRY(s, hipMalloc((void **)&s->blk_bnd, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
-        HIP_TRY(s, hipMalloc((void **)&s->blk_chk, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
-        HIP_TRY(s, hipMalloc((void **)&s->blk_fac, Bw * (size_t)N * BLK_FAC_ROWS * sizeof(double)));
-        s->blk_J = Jeff;
+        HIP_TRY(s, gmalloc(s, (void **)&s->blk_agg, Bw * Jeff * 3 * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, gmalloc(s, (void **)&s->blk_bnd, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, gmalloc(s, (void **)&s->blk_chk, Bw * (Jeff + 1) * BLK_MAT * sizeof(double)));
+        HIP_TRY(s, gmalloc(s, (void **)&s->blk_fac, Bw * (size_t)N * BLK_FAC_ROWS * sizeof(double)));
         for (auto &e : s->blk_ev)
             if (!e) HIP_TRY(s, hipEventCreate(&e));
+        s->blk_J = Jeff;             // (only now: a failed event creation must not leave a "ready" state with null events behind)
     }
     BlockLaunch bl{};
     bl.cp = (const Consts<double> *)s->d_consts;
@@ -1163,8 +1241,11 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
         HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
     }
     if (factors_out) HIP_TRY(s, hipMemcpyAsync(factors_out, s->blk_fac, (size_t)B * N * BLK_FAC_ROWS * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (boundary_out) HIP_TRY(s, hipMemcpyAsync(boundary_out, s->blk_bnd, (size_t)B * (Jeff + 1) * BLK_MAT * sizeof(double), hipMemcpyDeviceToDevice, st));
-    if (check_out) HIP_TRY(s, hipMemcpyAsync(check_out, s->blk_chk, (size_t)B * (Jeff + 1) * BLK_MAT * sizeof(double), hipMemcpyDeviceToDevice, st));
+    // boundary_out / check_out are the CALLER's [B][blocks + 1][256]: rows 0 .. Jeff of every instance are written (Jeff <= blocks is only
+    // known after the call), each instance at its own stride
+    const size_t row_in = (size_t)(Jeff + 1) * BLK_MAT * sizeof(double), row_out = (size_t)(blocks + 1) * BLK_MAT * sizeof(double);
+    if (boundary_out) HIP_TRY(s, hipMemcpy2DAsync(boundary_out, row_out, s->blk_bnd, row_in, row_in, (size_t)B, hipMemcpyDeviceToDevice, st));
+    if (check_out) HIP_TRY(s, hipMemcpy2DAsync(check_out, row_out, s->blk_chk, row_in, row_in, (size_t)B, hipMemcpyDeviceToDevice, st));
     if (ms_out) {
         HIP_TRY(s, hipEventSynchronize(s->blk_ev[3]));
         for (int i = 0; i < 3; i++) HIP_TRY(s, hipEventElapsedTime(&ms_out[i], s->blk_ev[i], s->blk_ev[i + 1]));

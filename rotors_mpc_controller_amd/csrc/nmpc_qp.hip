@@ -1,12 +1,13 @@
 // nmpc_qp.hip -- the kernels of nmpc_team_as.hpp that are built with the compiler's DEFAULT code generation: k_team_qp (the whole QP,
 // whole batch), k_team_qp_list (work-list continuation) and a second build of k_team_as.
 //
-// Why a translation unit of its own: nmpc_as.hip is compiled with -mllvm -amdgpu-mfma-vgpr-form (+9 % on the headline kernel).  That is
-// an internal LLVM option, and it MISCOMPILES some instantiations of this code: k_team_qp<per-stage, trajectories> built with it
-// faulted ("Memory access fault by GPU") on sim_num_steps = 3 / 4 inputs that the same sources built without it solve to 1e-14 of
-// the oracle (round 3, tools/dev/one_cfg.py; in round 2 it made the general kernel miscount its iterations).  So the flag is kept
-// for exactly ONE configuration - k_team_as at sim_num_steps <= 2, whose results a GPU test holds bit-equal to this file's build of
-// the same kernel (NMPC_AS_NOFLAG=1 selects it) - and nothing else is built with it.
+// Why a translation unit of its own: nmpc_as.hip is compiled with -mllvm -amdgpu-mfma-vgpr-form (+7 % on the headline kernel), an INTERNAL
+// LLVM option that is validated for exactly one configuration - k_team_as at sim_num_steps <= 2: bit-equal on the GPU to this file's build
+// of the same kernel (NMPC_AS_NOFLAG=1 selects it), and executed instruction by instruction on the CPU by tools/emu with every address
+// checked (tests/test_isa_emulation.py).  Everything else is built here, with the default code generation.  (Round 3 wrote that the flag
+// "miscompiles" k_team_qp<per-stage, trajectories>, after a GPU memory fault on sim_num_steps = 4 inputs.  Round 4 emulated that launch on
+// the flag build - all 256 workgroups, 32 M instructions, no access outside a buffer, the oracle's answers - and withdrew the claim: the
+// fault came from an uncommitted working tree.  DESIGN.md section 4.2 has the examination.)
 #include <hip/hip_runtime.h>
 
 #include "nmpc_as_launch.hpp"
@@ -18,8 +19,12 @@ namespace {
 // first launch of the default FP64 path: preparation + the first active-set attempt (nmpc_team_as.hpp).
 // OCC = waves per SIMD the register allocation allows: 2 (256 registers) pays once the batch supplies two waves
 // per SIMD (B >= 8192); below that one wave per SIMD is all there is and the 512-register build has no spills.
+// OCC = 3: the 256-register budget of OCC = 2 WITH the LDS stage cache (40 KB of LDS per wave keep it at one wave per SIMD anyway).  With
+// at most 256 registers the compiler's own, supported heuristic selects the VGPR form of the MFMAs (no accumulation registers exist for
+// the kernel) - the code shape the internal option -amdgpu-mfma-vgpr-form forces on nmpc_as.hip's 512-register build - and spills what
+// does not fit to scratch instead of accumulation registers.  NMPC_AS_BUILD=v256 selects it (shared linearisation only).
 template <bool SHARED, bool TRAJ, int OCC, class TI>
-__global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
+__global__ __launch_bounds__(64, OCC == 1 ? 1 : 2) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
                                                      TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg, int lm_off,
                                                      int pass_cap, double *tail_ts)
 {
@@ -29,7 +34,7 @@ __global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__res
     // (pass_cap > 0: long horizons - the attempt is handed to the block-parallel tail after that many passes, tail_ts its state rows)
     TailCtx tcx;
     tcx.cap = pass_cap; tcx.ts = tail_ts;
-    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, -2, tcx);
+    team_as<SHARED, TRAJ, OCC != 2, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, -2, tcx);
 }
 
 // The whole QP of every instance of the batch in one launch (team_as MODE 1): interior-point iterations in the tile form,
@@ -51,6 +56,9 @@ __global__ __launch_bounds__(64, 1) void k_team_qp_list(const Consts<double> *__
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = *wl.count;
+    // the usual case on the headline workload: nothing was handed over.  Every workgroup reads the same 0 (nobody appends while this
+    // kernel runs), the list needs no reset, and the launch ends on one scalar load instead of an atomic round trip per workgroup
+    if (n == 0) return;
     const int team = (threadIdx.x >> 2) & 3;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         const int e = base + team;
@@ -129,6 +137,7 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 #define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off, a.tail.cap, a.tail.ts)
     if (a.shared) {
         if (a.occ == 2) { if (a.traj) NMPC_LAUNCH_AS(true, true, 2); else NMPC_LAUNCH_AS(true, false, 2); }
+        else if (a.occ == 3) { if (a.traj) NMPC_LAUNCH_AS(true, true, 3); else NMPC_LAUNCH_AS(true, false, 3); }
         else { if (a.traj) NMPC_LAUNCH_AS(true, true, 1); else NMPC_LAUNCH_AS(true, false, 1); }
     } else {
         if (a.traj) NMPC_LAUNCH_AS(false, true, 1); else NMPC_LAUNCH_AS(false, false, 1);

@@ -221,6 +221,13 @@ class NmpcOcpSolver:
         """HIP events around the kernels of every solve (default on; stats() then reports kernel times)."""
         self._check(self._lib.nmpc_set_timing(self._h, int(bool(on))))
 
+    def guard_check(self) -> int:
+        """Damaged bytes of the canary bands around the handle's device buffers (handles created under NMPC_GUARD=<KiB>); -1 without."""
+        n = int(self._lib.nmpc_debug_guard_check(self._h))
+        if n > 0:
+            raise RuntimeError(self._lib.nmpc_last_error(self._h).decode())
+        return n
+
     def stats(self) -> dict:
         st = NmpcStats()
         self._check(self._lib.nmpc_get_stats(self._h, C.byref(st)))

@@ -22,7 +22,12 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
                 int bcast, const double *x_init, const double *u_init, double *u0, int32_t *status,
                 double *x_out, double *u_out, int32_t *iters, int shared)
 {
-    const size_t N = g.N, Bp = (B + 63) / 64 * 64;
+    // A thread owns CH lanes at a time in a PRIVATE workspace of CH lanes (row stride CH: one cache line per row, the whole
+    // workspace ~0.4 MB at N = 20, resident in its L2) - round 3 ran all lanes in one [rows][Bp] workspace, where a lane's rows
+    // lie Bp * 8 bytes apart (a TLB entry per row at Bp = 16384) and scaled 3.6x on 256 cores.  Nothing is allocated inside the
+    // loop over chunks.  Arithmetic per lane is unchanged: lane kernels only use w.Bp as the row stride.
+    constexpr int CH = 8;
+    const size_t N = g.N, Bp = CH;
     Consts<T> c;
     fill_consts(g, c);
     c.shared = (shared && !x_init) ? 1 : 0;
@@ -31,27 +36,35 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
                    hye = cv(yref_e, (bcast ? 1 : B) * NX);
     std::vector<T> hxi, hui;
     if (x_init) { hxi = cv(x_init, (size_t)B * (N + 1) * NX); hui = cv(u_init, (size_t)B * N * NU); }
-    std::vector<T> AB(N * AB_ROWS * Bp), bv(N * NX * Bp), qr((N * QR_ROWS + NX) * Bp), xl((N + 1) * NX * Bp),
-        ul(N * NU * Bp), LM(N * LM_ROWS * Bp), iv(N * IV_ROWS * Bp);
-    std::vector<int32_t> it(Bp), st(Bp);
+    std::vector<int32_t> it(B), st(B);
     std::vector<T> ou0((size_t)B * NU), oxo((size_t)B * (N + 1) * NX), ouo((size_t)B * N * NU);
-    Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), it.data(), st.data(), nullptr, nullptr, nullptr};
-    Inputs<T> in{hx0.data(), hy.data(), hye.data(), x_init ? hxi.data() : nullptr, x_init ? hui.data() : nullptr, bcast};
-    Outputs<T> out{ou0.data(), oxo.data(), ouo.data()};
-    // (instances are independent; OpenMP over lanes is what bench.py's second cpu_baseline row times)
-#pragma omp parallel for schedule(dynamic, 16)
-    for (int lane = 0; lane < B; lane++) lane_prepare(c, w, in, lane);
-    if (g.flags & NMPC_FLAG_CONDENSED_QP) {
-        CondWork<T> cw;
-        const int N2 = (g.qp_cond_N > 0 && g.qp_cond_N < g.N) ? g.qp_cond_N : g.N;
-        std::vector<T> cbuf((size_t)cond_layout(cw, g.N, N2) * Bp);
+    const bool cond = (g.flags & NMPC_FLAG_CONDENSED_QP) != 0;
+    CondWork<T> cw0;
+    const int N2 = (g.qp_cond_N > 0 && g.qp_cond_N < g.N) ? g.qp_cond_N : g.N;
+    const size_t cond_n = cond ? (size_t)cond_layout(cw0, g.N, N2) * Bp : 0;
+    // (instances are independent; OpenMP over chunks of lanes is what bench.py's second cpu_baseline row times)
+#pragma omp parallel
+    {
+        std::vector<T> AB(N * AB_ROWS * Bp), bv(N * NX * Bp), qr((N * QR_ROWS + NX) * Bp), xl((N + 1) * NX * Bp),
+            ul(N * NU * Bp), LM(N * LM_ROWS * Bp), iv(N * IV_ROWS * Bp), cbuf(cond_n);
+        int32_t itc[CH], stc[CH];
+        CondWork<T> cw = cw0;
         cw.base = cbuf.data();
         cw.Bp = (int)Bp;
-#pragma omp parallel for schedule(dynamic, 16)
-        for (int lane = 0; lane < B; lane++) lane_cond_ipm(c, w, cw, out, lane);
-    } else {
-#pragma omp parallel for schedule(dynamic, 16)
-        for (int lane = 0; lane < B; lane++) lane_ipm(c, w, out, lane);
+#pragma omp for schedule(static)
+        for (int c0 = 0; c0 < B; c0 += CH) {
+            const int n = B - c0 < CH ? B - c0 : CH;
+            Work<T> w{(int)Bp, AB.data(), bv.data(), qr.data(), xl.data(), ul.data(), LM.data(), iv.data(), itc, stc, nullptr, nullptr, nullptr};
+            Inputs<T> in{hx0.data() + (size_t)c0 * NX, bcast ? hy.data() : hy.data() + (size_t)c0 * N * NY,
+                         bcast ? hye.data() : hye.data() + (size_t)c0 * NX,
+                         x_init ? hxi.data() + (size_t)c0 * (N + 1) * NX : nullptr, x_init ? hui.data() + (size_t)c0 * N * NU : nullptr, bcast};
+            Outputs<T> out{ou0.data() + (size_t)c0 * NU, oxo.data() + (size_t)c0 * (N + 1) * NX, ouo.data() + (size_t)c0 * N * NU};
+            for (int lane = 0; lane < n; lane++) {
+                lane_prepare(c, w, in, lane);
+                if (cond) lane_cond_ipm(c, w, cw, out, lane); else lane_ipm(c, w, out, lane);
+                it[c0 + lane] = itc[lane]; st[c0 + lane] = stc[lane];
+            }
+        }
     }
     for (size_t i = 0; i < ou0.size(); i++) u0[i] = ou0[i];
     if (x_out) for (size_t i = 0; i < oxo.size(); i++) x_out[i] = oxo[i];

@@ -116,3 +116,52 @@ def test_equal_shards_of_4096_all_gather_commands_and_grouped_gather():
         np.testing.assert_array_equal(g_s[r * 4096:(r + 1) * 4096], ref["status"])
         for t in range(3):
             np.testing.assert_array_equal(grouped[r, t], ref["u0"] + float(t))       # [world][G][B][4], as bench.py indexes it
+
+
+def _worker_inplace(rank, world, port, q):
+    """The default exchange of bench.py's multi-rank run, on gloo: every rank's solve writes its commands straight into ITS slot of
+    a gather buffer [world][B][4], the all-gather is in place (input = that slot of the output), two buffers alternate between
+    ticks.  Same tensor expressions as bench.py (gat2[b][rank], gat2[b].view(world * B, 4))."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import hostsim as H
+    from rotors_mpc_controller_amd.distributed import rank_seed
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER
+    B = 96
+    cfg = _lib.default_config()
+    yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
+    u0 = torch.from_numpy(H.solve_batch(cfg, sample_x0(B, rank_seed(rank), **NEAR_HOVER), yref, ye)["u0"])
+    gat2 = [torch.full((world, B, 4), float("nan"), dtype=torch.float64) for _ in range(2)]
+    seen = []
+    for t in range(4):                           # four ticks: buffers 0, 1, 0, 1; tick t carries u0 + t
+        b = t & 1
+        gat2[b][rank].copy_(u0 + float(t))       # "the solve writes into this rank's slot"
+        dist.all_gather_into_tensor(gat2[b].view(world * B, 4), gat2[b][rank])
+        seen.append(gat2[b].clone())
+    if rank == 0:
+        q.put(torch.stack(seen).numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_in_place_gather_buffer_layout_of_the_default_exchange():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_inplace, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    seen = q.get(timeout=300)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    from tests import hostsim as H
+    from rotors_mpc_controller_amd.distributed import rank_seed
+    from rotors_mpc_controller_amd.synthetic import NEAR_HOVER
+    cfg = _lib.default_config()
+    yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
+    assert seen.shape == (4, 2, 96, 4)
+    for r in range(2):
+        ref = H.solve_batch(cfg, sample_x0(96, rank_seed(r), **NEAR_HOVER), yref, ye)["u0"]
+        for t in range(4):
+            np.testing.assert_array_equal(seen[t, r], ref + float(t))      # slot r of tick t's buffer = rank r's commands of that tick

@@ -51,3 +51,17 @@ def test_rccl_path_with_one_rank():
     # one collective per tick (solve straight into the gather buffer, solve + all-gather on one stream, replayed from a HIP
     # graph where RCCL can be captured) must not cost more than a tenth of the rate without any exchange
     assert d["value"] >= 0.9 * d["secondary"]["no_exchange"]["value"], (d["value"], d["secondary"]["no_exchange"]["value"], d["config"]["exchange"])
+
+
+def test_device_time_of_the_rccl_path_covers_every_tick():
+    """20 steps against an 8-tick graph leave 4 ticks that are run eagerly: they must lie inside the two HIP events that give
+    device_ms_per_step (round 3 ran them after the closing event: device time, roofline.kernel_ms and frac of every N > 1 line of
+    the driver's 20-step runs were 20 % off).  Device time per step then sits just under the wall time per step."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(NMPC_BENCH_FORCE_DIST="1", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK="0", WORLD_SIZE="1",
+               LOCAL_RANK="0")
+    d = _run(env, "--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-secondary")
+    assert "in-place all-gather per tick" in d["config"]["exchange"]
+    assert 0.88 * d["ms_per_step"] <= d["device_ms_per_step"] <= 1.02 * d["ms_per_step"], (d["device_ms_per_step"], d["ms_per_step"])

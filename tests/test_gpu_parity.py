@@ -487,8 +487,8 @@ def test_plain_ipm_iteration_counts_match_oracle():
 
 @pytest.mark.parametrize("share", [1, 0])
 def test_flag_build_of_the_active_set_kernel_is_bit_equal_to_the_default_codegen_build(share, monkeypatch):
-    """k_team_as is the one kernel built with -mllvm -amdgpu-mfma-vgpr-form (nmpc_as.hip): an internal compiler option that
-    miscompiled other instantiations of the same sources (nmpc_qp.hip has the story).  The same kernel is also built with the
+    """k_team_as is the one kernel built with -mllvm -amdgpu-mfma-vgpr-form (nmpc_as.hip): an internal compiler option, validated for this
+    kernel only (nmpc_qp.hip and DESIGN.md section 4.2 have the story).  The same kernel is also built with the
     default code generation; NMPC_AS_NOFLAG=1 selects that build.  Same arithmetic, different register placement: every output
     bit must agree - cold, warm-started, trajectories, pass statistics."""
     yref, ye = hover(_lib.default_config())
@@ -508,3 +508,36 @@ def test_flag_build_of_the_active_set_kernel_is_bit_equal_to_the_default_codegen
         np.testing.assert_array_equal(b0[key], b1[key])
     np.testing.assert_array_equal(p0, p1)
     np.testing.assert_array_equal(q0, q1)
+
+
+@pytest.mark.parametrize("polish", [0, 1])
+@pytest.mark.parametrize("steps", [3, 4])
+def test_three_and_four_integrator_steps_per_stage_linearisation_with_trajectories(steps, polish, monkeypatch):
+    """Regression test of the one GPU memory fault this repository has recorded (round 3, gpurun_out/qp_check2.log: k_team_qp<per-stage,
+    trajectories>, sim_num_steps = 4, qp_polish = 0, B = 256, aggressive seed 8 - then built with -mllvm -amdgpu-mfma-vgpr-form; DESIGN.md
+    section 4.2 has what was examined).  More than two integrator steps take EvLayout<4> of the evaluation-point buffer (half the
+    stages per chunk, twice the room per stage; include/rotors_nmpc.h accepts sim_num_steps <= 4, controller.py:188 ships 2).
+    Per-stage linearisation + trajectories, plain interior point (k_team_qp) and the default path (k_team_as + k_team_qp_list), cold
+    and warm-started, against the oracle at 1e-9; statuses and interior-point iteration counts equal.  The handle's buffers sit
+    between 64 KiB canary bands (NMPC_GUARD): no kernel of either solve stores outside a buffer."""
+    B = 256
+    monkeypatch.setenv("NMPC_GUARD", "64")
+    s = make_solver(sim_num_steps=steps, qp_polish=polish, flags=_lib.FLAG_TEAM_MAPPING, max_batch=B)
+    c = oracle_cfg(polish=bool(polish), sim_num_steps=steps)
+    yref, ye = hover(s.config)
+    x0 = sample_x0(B, 8, **AGGRESSIVE)
+    o1 = s.solve_batch(x0, yref, ye, want_traj=True)
+    it1 = s.iterations()
+    r1 = O.solve_batch(c, x0, yref, ye, want_traj=True, nthreads=8)
+    o2 = s.solve_batch(x0, yref, ye, x_init=o1["x"], u_init=o1["u"], want_traj=True)
+    it2 = s.iterations()
+    r2 = O.solve_batch(c, x0, yref, ye, x_init=r1["x"], u_init=r1["u"], want_traj=True, nthreads=8)
+    for o, r, it in ((o1, r1, it1), (o2, r2, it2)):
+        np.testing.assert_array_equal(o["status"], r["status"])
+        assert (o["status"] == 0).all()
+        np.testing.assert_allclose(o["u0"], r["u0"], rtol=0, atol=TOL_U)
+        np.testing.assert_allclose(o["x"], r["x"], rtol=0, atol=TOL_X)
+        np.testing.assert_allclose(o["u"], r["u"], rtol=0, atol=TOL_X)
+        np.testing.assert_array_equal(it, r["iters"])
+    assert s.guard_check() == 0
+    s.close()

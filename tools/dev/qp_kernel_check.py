@@ -38,6 +38,8 @@ def run(name, over, orc_over, dist, seed, N=20, warm=False, env=None):
         r2 = O.solve_batch(c, x0, yref, ye, x_init=r["x"], u_init=r["u"], want_traj=True, nthreads=8)
         st = s.stats()
         rep("warm", o2, r2, s.iterations())
+    g = s.guard_check()
+    if g == 0: print(f"{name:34s} guard bands clean", flush=True)
     s.close()
 SH = _lib.FLAG_TEAM_MAPPING | _lib.FLAG_SHARE_COLD_START
 for dist, nm, seed in ((NEAR_HOVER, "near", 0), (AGGRESSIVE, "aggr", 1), (WILD, "wild", 2)):
