@@ -29,13 +29,15 @@
 // The factors are the ones the sequential sweep of nmpc_team_as.hpp leaves (Mbar' tiles, L^-1 tile), equal to rounding times the
 // conditioning of the boundary update; tests/test_gpu_block.py compares them at N = 600.
 //
-// The stage below is the pins variant of sweepA's stage in nmpc_team_as.hpp (same products, same order), restated here because
-// that one is a lambda over the solver's pass state.  Used by nmpc_block_factor_device (a building block with its own entry point)
-// and, in tail mode, by every long-horizon solve (N >= 160: the block-parallel tail).
+// The stage itself is nmpc_stage.hpp - the ONE source of the factor stage, shared with sweepA of nmpc_team_as.hpp (until round 3 it was
+// restated here): a stage factorised by a block sweep has the bits the solver's own sweep would give it.  Used by
+// nmpc_block_factor_device (a building block with its own entry point) and, in tail mode, by every long-horizon solve (N >= 160: the
+// block-parallel tail).
 #pragma once
 
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
+#include "nmpc_stage.hpp"
 
 namespace nmpc {
 
@@ -179,6 +181,9 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     }
     if (r == 0) sh[ZSLOT] = T(0);
     const T Idt = (ta == tc) ? T(1) : T(0);
+    StageLane SL;                                     // per-lane constants of the factor stage (nmpc_stage.hpp)
+    SL.ta = ta; SL.tc = tc; SL.dt_v = dt_v; SL.Idt = Idt; SL.Ihalf = (ta == tc) ? T(0.5) : T(0); SL.Rd_a = Rd_a; SL.lb_a = lb_a; SL.ub_a = ub_a; SL.lbj = lbj; SL.ubj = ubj;
+    NMPC_UNROLL for (int t = 0; t < 4; t++) { SL.natR[t] = natR[t]; SL.Qdg[t] = Qdg[t]; SL.iq_col[t] = iq_col[t]; SL.iq_row[t] = iq_row[t]; }
     auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
     auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
     T pfs[12];
@@ -234,113 +239,39 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     T gm = 0;
     bool nanp = false;
     for (int k = ks; k >= s; k--) {
-        T Aq0[4], Aq1[4], Bt[4];
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
+        T Aq0[4], Aq1b[4], Bt[4];
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
         const int kn = k > s ? k - 1 : s;                   // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
         fetch_stage(kn);
-        const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
-        T rk = Wr_a * (ul - n_yu);
-        const T q_r = Wq_r * (n_xl - n_yx);
+        StageIn sin;
+        sin.ul = n_ul; sin.pc = n_pc; sin.pca = n_pca; sin.ulc = n_ulc; sin.u_it = n_u; sin.ll_it = n_ll; sin.lu_it = n_lu;
+        T rk = Wr_a * (sin.ul - n_yu);
+        sin.q_r = Wq_r * (n_xl - n_yx);
         asm volatile("" : "+v"(rk));
+        sin.rk = rk;
         n_yx = (T)yr[(size_t)kn * NY + rr]; n_yu = (T)yr[(size_t)kn * NY + NX + ta];
         n_xl = xlin(kn); n_ul = ulin(kn, ta);
         n_pc = tIV[kn * IV_ROWS + 16 + j]; n_pca = tIV[kn * IV_ROWS + 16 + ta]; n_ulc = ulin(kn, j);
         if (TAIL) { const T *ivn = tIV + kn * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
-        sh[r] = q_r;
-        // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps R_jj so that u_j = bound
-        const bool pinned_a = !ipm && pca != T(0), pinned = !ipm && pc != T(0);
-        const T vpin_a = pca < T(0) ? lb_a - ul : ub_a - ul;
-        const T vpin_c = pc < T(0) ? lbj - ulc : ubj - ulc;
-        const T mask_a = pinned_a ? T(0) : T(1), mask_c = pinned ? T(0) : T(1);
-        T D_a = Rd_a, rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
-        if (TAIL) {
-            // barrier terms of the interior-point iteration: D = R + lam_l / t_l + lam_u / t_u, rhat = r - (D - R) u
-            const Pair<T> pr(u_it, ll_it, lu_it, lb_a - ul, ub_a - ul);
-            const T sg = pr.kl + pr.ku;
-            D_a = ipm ? Rd_a + sg : D_a;
-            rhat_a = ipm ? rk - sg * u_it : rhat_a;
-        }
-        const bool any_pins = __ballot(pinned) != 0;
-        if (any_pins) {
-            const T vp = pinned ? vpin_c : T(0);
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                const T sm = quad_sum(Bt[kt] * vp);
-                if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
-            }
-        }
-        T WB[4], Hr = 0;
-        NMPC_UNROLL for (int it = 0; it < 4; it++) {
-            T aB = 0;
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
-            WB[it] = aB;
-        }
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
-        const T Hrm = mask_a * mask_c * Hr;
-        if (!AGG) gm = fmax(gm, fabs(Hrm));              // growth certificate: max |B'PB| as the free inputs see it
-        const T Huu = ((ta == tc) ? D_a : T(0)) + Hrm;
-        T W0[4], W1[4];
-        NMPC_UNROLL for (int it = 0; it < 4; it++) {
-            T a0 = 0, a1 = 0;
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
-                a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
-            }
-            W0[it] = a0; W1[it] = a1;
-        }
-        T PA[4][4];
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-            PA[kt][0] = Pt[kt][0];
-            PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
-            PA[kt][2] = W0[kt];
-            PA[kt][3] = W1[kt];
-        }
-        T X0raw = 0, X[4];
-        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-            T a = 0;
-            if (jt == 0) a = mfma44(WB[0], Idt, T(0));
-            else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
-            else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
-            if (jt == 0) X0raw = a;
-            X[jt] = mask_a * a;
-            // gradient rows of the pinned inputs for the multiplier check of the forward sweep
-            if (TAIL && !AGG) { if (any_pins) tLM[k * TLM_ROWS + TLM_G + jt * 16 + tc * 4 + ta] = a; }
-        }
-        if (TAIL && !AGG) { if (any_pins) tLM[k * TLM_ROWS + TLM_G + 64 + tc * 4 + ta] = Hr; }
-        if (tc == 3) X[3] += rhat_a;
-        T Pn[4][4];
-        {
-            T qcol[4], qrow[4];
-            NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
-            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
-                T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
-                if (jt >= 2) {
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                        if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                        if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
-                    }
+        // the stage: nmpc_stage.hpp, the source the solver's own backward sweep uses (pins variant; in tail mode the barrier terms of an
+        // interior-point iteration instead, chosen per team by its tail state)
+        StageOut so;
+        auto sink = stage_sink(
+            [&](int jt, T a) { if (TAIL && !AGG) tLM[k * TLM_ROWS + TLM_G + jt * 16 + tc * 4 + ta] = a; },      // gradient rows of the pinned inputs
+            [&](T hr) { if (TAIL && !AGG) tLM[k * TLM_ROWS + TLM_G + 64 + tc * 4 + ta] = hr; },
+            [&](const StageOut &f) {
+                if (!AGG) {
+                    T *fk = TAIL ? tLM + (size_t)k * TLM_ROWS + TLM_MT : fac + (size_t)k * BLK_FAC_ROWS;
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) fk[jt * 16 + tc * 4 + ta] = f.M[jt];        // where a forward sweep reads it transposed
+                    fk[64 + r] = f.Zt;                                                                      // Y' = L^-1 as a tile
+                    if (TAIL) tLM[(size_t)k * TLM_ROWS + TLM_RINV + ta + (tc == 0 ? 0 : 4)] = f.ra;        // 1 / d_a for the corrector's solves
                 }
-                Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
-                Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
-                Pn[2][jt] = a2;
-                Pn[3][jt] = a3;
-            }
-        }
-        const Ldl4 f = ldl4<false>(Huu, sHg, ta, tc, false, ok);
-        nanp |= f.nan;
-        const T Y = f.Y;
-        const T ra = ta == 0 ? f.r0 : (ta == 1 ? f.r1 : (ta == 2 ? f.r2 : f.r3));
-        T M0[4], M[4];
-        NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-            M0[jt] = mfma44(Y, X[jt], T(0));
-            M[jt] = ra * M0[jt];
-        }
-        if (!AGG) {
-            T *fk = TAIL ? tLM + (size_t)k * TLM_ROWS + TLM_MT : fac + (size_t)k * BLK_FAC_ROWS;
-            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) fk[jt * 16 + tc * 4 + ta] = M[jt];        // where a forward sweep reads it transposed
-            fk[64 + r] = mfma44(Y, Idt, T(0));                                                  // Y' = L^-1 as a tile
-            if (TAIL) tLM[(size_t)k * TLM_ROWS + TLM_RINV + ta + (tc == 0 ? 0 : 4)] = ra;        // 1 / d_a for the corrector's solves
-        }
+            });
+        riccati_factor_stage<true, TAIL, false, !AGG>(SL, sh, sHg, r, Aq0, Aq1b, Bt, sin, !ipm, ipm, Pt, gm, ok, nanp, so, sink);
+        const T Y = so.Y, ra = so.ra, mask_a = so.mask_a;
+        const T (&Aq1)[4] = so.Aq1;
+        const T (&M)[4] = so.M;
+        (void)Y; (void)ra; (void)mask_a; (void)Aq1; (void)M;
         if constexpr (AGG) {
             // G' = Bm' Phi (rows of pinned inputs masked), N0 = L^-1 G', Nn = Dh^-1 N0:  C += N0' Nn,  Phi <- Abar' Phi - M' N0
             T N0[4], Nn[4];
@@ -365,21 +296,8 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
                 Pq[2][it] = a2;
                 Pq[3][it] = a3;
             }
-            T Mneg[4];
-            NMPC_UNROLL for (int t = 0; t < 4; t++) Mneg[t] = -M[t];
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                NMPC_UNROLL for (int it = 0; it < 4; it++) Ph[jt][it] = mfma44(Mneg[jt], N0[it], Pq[jt][it]);
-            }
-        }
-        {
-            T Mn[4];
-            NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
-            NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
-            }
-            NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
-            NMPC_UNROLL for (int it = 1; it < 4; it++) {
-                NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
+                NMPC_UNROLL for (int it = 0; it < 4; it++) Ph[jt][it] = mfma44_na(M[jt], N0[it], Pq[jt][it]);
             }
         }
         NMPC_WSYNC();

@@ -144,6 +144,9 @@ __device__ __forceinline__ float fast_rsqrt(float x)
 // reaches the full FP64 rate with this instruction, but only half of it with v_fma_f64).
 __device__ __forceinline__ double mfma44(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ float mfma44(float, float, float c) { return c; }   // FP32 keeps the VALU form
+// (-X)'Y + C: the FP64 MFMAs take a negation per operand in their BLGP field (neg:[1,0,0]) - exact, and one v_xor_b32 per tile saved
+__device__ __forceinline__ double mfma44_na(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1); }
+__device__ __forceinline__ float mfma44_na(float, float, float c) { return c; }
 
 // padded state order of the tile form: p(3) _ | v(3) _ | q(4) | omega(3) 1   (index 15 is the homogeneous
 // coordinate that carries b, p and the gradients); natural index of element e of tile t, -1 for a pad

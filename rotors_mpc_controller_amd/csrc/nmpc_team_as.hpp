@@ -31,6 +31,7 @@
 
 #include "nmpc_ipm.hpp"
 #include "nmpc_team.hpp"
+#include "nmpc_stage.hpp"
 
 namespace nmpc {
 
@@ -193,7 +194,9 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     }
     if (r == 0) sRed[32] = T(0);
     const T Idt = (ta == tc) ? T(1) : T(0);
-    const T HuuD = (ta == tc) ? Rd_a : T(0);          // diagonal of Huu without pins
+    StageLane SL;                                     // per-lane constants of the factor stage (nmpc_stage.hpp)
+    SL.ta = ta; SL.tc = tc; SL.dt_v = dt_v; SL.Idt = Idt; SL.Ihalf = (ta == tc) ? T(0.5) : T(0); SL.Rd_a = Rd_a; SL.lb_a = lb_a; SL.ub_a = ub_a; SL.lbj = lbj; SL.ubj = ubj;
+    NMPC_UNROLL for (int t = 0; t < 4; t++) { SL.natR[t] = natR[t]; SL.Qdg[t] = Qdg[t]; SL.iq_col[t] = iq_col[t]; SL.iq_row[t] = iq_row[t]; }
     NMPC_STAMP(2)
 
     // =========================== preparation: linearise Ns shooting intervals
@@ -454,188 +457,27 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 if (PINS) { n_pc = tIV[(k - 1) * IV_ROWS + 16 + j]; n_pca = tIV[(k - 1) * IV_ROWS + 16 + ta]; n_ulc = ulin(k - 1, j); }
                 if (IPMV) { const T *ivn = tIV + (k - 1) * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
             }
-            T mask_a = T(1), mask_c = T(1), D_a = Rd_a, rhat_a = rk;
-            if (IPMV) {
-                // barrier terms of the interior-point iteration: D = R + lam_l / t_l + lam_u / t_u, rhat = r - (D - R) u
-                const Pair<T> pr(u_it, ll_it, lu_it, lb_a - ul, ub_a - ul);
-                const T sg = pr.kl + pr.ku;
-                D_a = Rd_a + sg;
-                rhat_a = rk - sg * u_it;
-            }
-            bool any_pins = false;
-            T Aq1[4];
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = Aq1b[kt];
-            if (!LAST) sh[r] = q_r;                  // natural row rr of the stage gradient
-            if (PINS) {
-                // pinned inputs leave B (free mask) and enter through b (pinned value); their own row keeps
-                // R_jj so that u_j = bound
-                const bool pinned_a = pol && pca != T(0), pinned = pol && pc != T(0);      // input a | input c of this lane
-                const T vpin_a = pca < T(0) ? lb_a - ul : ub_a - ul;
-                const T vpin_c = pc < T(0) ? lbj - ulc : ubj - ulc;
-                mask_a = pinned_a ? T(0) : T(1); mask_c = pinned ? T(0) : T(1);
-                D_a = Rd_a;
-                rhat_a = pinned_a ? -Rd_a * vpin_a : rk;
-                any_pins = __ballot(pinned) != 0;
-                if (any_pins) {                      // pinned inputs enter through b (column 15 of Abar)
-                    const T vp = pinned ? vpin_c : T(0);
-                    NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                        const T sm = quad_sum(Bt[kt] * vp);
-                        if (tc == 3 && natR[kt] >= 0) Aq1[kt] += sm;
+            StageIn sin;
+            sin.rk = rk; sin.q_r = q_r; sin.ul = ul; sin.ulc = ulc; sin.pc = pc; sin.pca = pca; sin.u_it = u_it; sin.ll_it = ll_it; sin.lu_it = lu_it;
+            StageOut so;
+            // the stage itself: nmpc_stage.hpp (one source for this sweep and the block sweeps of nmpc_block.hpp).  Stores happen where they
+            // always did: gradient rows of pinned stages while X is formed, the factors as soon as M is final
+            auto sink = stage_sink(
+                [&](int jt, T a) { lmk[TLM_G + jt * 16 + tc * 4 + ta] = a; },
+                [&](T hr) { lmk[TLM_G + 64 + tc * 4 + ta] = hr; },
+                [&](const StageOut &f) {
+                    NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                        // stored where the forward sweep reads it transposed
+                        if (LDSST) sLM[k * LMR + jt * 16 + tc * 4 + ta] = f.M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = f.M[jt];
                     }
-                }
-            }
-            // P B and Hr = B'PB first: the Cholesky below depends on nothing else
-            T WB[4], Hr = 0;
-            NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                T aB = 0;
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) aB = mfma44(Pt[kt][it], Bt[kt], aB);
-                WB[it] = aB;
-            }
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Hr = mfma44(Bt[kt], WB[kt], Hr);
-            const T Hrm = PINS ? mask_a * mask_c * Hr : Hr;
-            gm = fmax(gm, fabs(Hrm));                    // growth certificate: max |B'PB| as the free inputs see it
-            const T Huu = ((PINS || IPMV) ? ((ta == tc) ? D_a : T(0)) : HuuD) + Hrm;
-            if (tc <= ta) sHg[lidx(ta, tc)] = Huu;
-            NMPC_WSYNC();
-            T Lf[10];
-            NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = sHg[i];
-#if defined(NMPC_DEBUG_NAN) && defined(__HIP_DEVICE_COMPILE__) && defined(NMPC_PROFILE)
-            {   // diagnostic build (tools/dev/nan_probe.py): first stage at which a NaN reaches the factor stage, and where
-                bool fa = false, fp = false, fh = false;
-                NMPC_UNROLL for (int t = 0; t < 4; t++) fa |= !(Aq0[t] == Aq0[t]) || !(Aq1[t] == Aq1[t]) || !(Bt[t] == Bt[t]);
-                NMPC_UNROLL for (int a_ = 0; a_ < 4; a_++) { NMPC_UNROLL for (int b_ = 0; b_ < 4; b_++) fp |= !(Pt[a_][b_] == Pt[a_][b_]); }
-                NMPC_UNROLL for (int i = 0; i < 10; i++) fh |= !(Lf[i] == Lf[i]);
-                const int code = (__ballot(fa) & team_mask) ? 1 : ((__ballot(fp) & team_mask) ? 2 : ((__ballot(fh) & team_mask) ? 3 : 0));
-                if (prof_acc_[5] == 0 && code) prof_acc_[5] = 1000000 + pass * 100000 + k * 100 + code;
-            }
-#endif
-            // W = Pbar * [Aq0 | Aq1]  (Pbar symmetric: its tile (kt,it) read transposed is tile (it,kt)).  Tile (3,0) of Abar -
-            // d omega+ / d q and the homogeneous row - is identically zero (the body rates do not depend on the attitude):
-            // its products are left out here, in the (q,w) x (q,w) block below and in the forward sweep (94 MFMAs per stage)
-            T W0[4], W1[4];
-            NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                T a0 = 0, a1 = 0;
-                NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                    if (kt < 3) a0 = mfma44(Pt[kt][it], Aq0[kt], a0);
-                    a1 = mfma44(Pt[kt][it], Aq1[kt], a1);
-                }
-                W0[it] = a0; W1[it] = a1;
-            }
-            T PA[4][4];
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                PA[kt][0] = Pt[kt][0];
-                PA[kt][1] = dt_v * Pt[kt][0] + Pt[kt][1];
-                PA[kt][2] = W0[kt];
-                PA[kt][3] = W1[kt];
-            }
-            // X = B'(Pbar Abar) (column 15: B'h)
-            T X0raw = 0;
-            T X[4];
-            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                T a = 0;
-                if (jt == 0) a = mfma44(WB[0], Idt, T(0));
-                else if (jt == 1) a = mfma44(WB[1], Idt, T(0)) + dt_v * X0raw;
-                else { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) a = mfma44(Bt[kt], PA[kt][jt], a); }
-                if (jt == 0) X0raw = a;
-                X[jt] = PINS ? mask_a * a : a;
-                // gradient rows of the pinned inputs for the multiplier check of the forward sweep
-                if (PINS) { if (any_pins) lmk[TLM_G + jt * 16 + tc * 4 + ta] = a; }
-            }
-            if (PINS) { if (any_pins) lmk[TLM_G + 64 + tc * 4 + ta] = Hr; }
-            if (tc == 3) X[3] += rhat_a;                                   // gu = rhat + mask * B'h
-            // the (q,w) x (q,w) tiles of Abar'(Pbar Abar) and the (p,v) rows: independent of the Cholesky
-            T Pn[4][4];
-            if (!LAST) {
-                T qcol[4], qrow[4];       // column / row 15 of Qbar: the stage gradient, zero elsewhere (read from a zero slot)
-                NMPC_UNROLL for (int t = 0; t < 4; t++) { qcol[t] = sh[iq_col[t]]; qrow[t] = sh[iq_row[t]]; }
-                // Pbar_k = Qbar + Abar'(Pbar Abar) - Mbar'Mbar, assembled in the MFMA accumulators: the ten tiles on and above
-                // the diagonal only (see the update below)
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                    T a2 = (jt == 2 ? Qdg[2] : T(0)) + (jt == 3 ? qcol[2] : T(0));
-                    T a3 = (jt == 3 ? Qdg[3] + qcol[3] + qrow[3] : T(0));
-                    if (jt >= 2) {
-                        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                            if (kt < 3) a2 = mfma44(Aq0[kt], PA[kt][jt], a2);
-                            if (jt == 3) a3 = mfma44(Aq1[kt], PA[kt][jt], a3);
-                        }
+                    if (LDSST) sLM[k * LMR + 64 + r] = f.Zt; else lmk[TLM_Z + r] = f.Zt;
+                    if (IPMV) {              // 1 / d_a for the corrector's solves (lanes (a, c != 0) store the same value to a spare slot)
+                        const int rs = ta + (tc == 0 ? 0 : 4);
+                        if (LDSST) sLM[k * LMR + 80 + rs] = f.ra; else lmk[TLM_RINV + rs] = f.ra;
                     }
-                    Pn[0][jt] = PA[0][jt] + (jt == 0 ? Qdg[0] : T(0)) + (jt == 3 ? qcol[0] : T(0));
-                    Pn[1][jt] = jt >= 1 ? dt_v * PA[0][jt] + PA[1][jt] + (jt == 1 ? Qdg[1] : T(0)) + (jt == 3 ? qcol[1] : T(0)) : T(0);
-                    Pn[2][jt] = a2;
-                    Pn[3][jt] = a3;
-                }
-            }
-            // H_uu = L D L' (unit L), replicated in every lane of the team.  Square-root free on purpose: a pivot costs
-            // v_rcp_f64 + two Newton steps (4 FMAs) where the Cholesky form cost v_rsq_f64 + 8, the inverse of a UNIT
-            // triangle needs 4 FMAs where the general one needed 16 operations, and FP64 vector instructions are paid
-            // in full here - they share the SIMD's double-precision pipe with the MFMAs.
-            // c_ij = l_ij d_j are the unscaled column entries.
-            T r0, r1, r2, r3, l10, l20, l30, l21, l31, l32;
-            {
-                const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
-                const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
-                auto pivot = [&](T d) -> T {
-                    const bool pos = d > T(0);
-                    ok &= pos; nanp |= !(d == d);
-                    return fast_rcp(pos ? d : T(1));
-                };
-                r0 = pivot(h00);
-                l10 = h10 * r0; l20 = h20 * r0; l30 = h30 * r0;
-                r1 = pivot(h11 - l10 * h10);
-                const T c21 = h21 - l20 * h10, c31 = h31 - l30 * h10;
-                l21 = c21 * r1; l31 = c31 * r1;
-                r2 = pivot(h22 - l20 * h20 - l21 * c21);
-                const T c32 = h32 - l30 * h20 - l31 * c21;
-                l32 = c32 * r2;
-                r3 = pivot(h33 - l30 * h30 - l31 * c31 - l32 * c32);
-            }
-            // Y = L^-T as a tile: lane (a,c) holds (L^-1)[c][a].  The inverse of the unit triangle in closed form and
-            // one select by the lane's (c,a): straight-line code - a forward substitution on the unit vector e_a, as
-            // the general kernel does it, compiles to lane-divergent branches that cut the stage's scheduling region
-            T Y;
-            {
-                const T i10 = -l10, i21 = -l21, i32 = -l32;
-                const T i20 = -(l20 + l21 * i10);
-                const T i31 = -(l31 + l32 * i21);
-                const T i30 = -(l30 + l31 * i10 + l32 * i20);
-                const int e = tc * 4 + ta;           // (row c, column a) of L^-1
-                Y = (ta == tc) ? T(1) : T(0);
-                Y = e == 4 ? i10 : Y;  Y = e == 8 ? i20 : Y;  Y = e == 9 ? i21 : Y;
-                Y = e == 12 ? i30 : Y; Y = e == 13 ? i31 : Y; Y = e == 14 ? i32 : Y;
-            }
-            // M0 = L^-1 X, M = D^-1 M0 (row a of the tile by 1 / d_a): the feedback is u = -L^-T (M xbar), the Riccati
-            // update subtracts M0' M
-            const T ra = ta == 0 ? r0 : (ta == 1 ? r1 : (ta == 2 ? r2 : r3));
-            T M0[4], M[4];
-            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
-                M0[jt] = mfma44(Y, X[jt], T(0));
-                M[jt] = ra * M0[jt];
-                // stored where the forward sweep reads it transposed
-                if (LDSST) sLM[k * LMR + jt * 16 + tc * 4 + ta] = M[jt]; else lmk[TLM_MT + jt * 16 + tc * 4 + ta] = M[jt];
-            }
-            const T Zt = mfma44(Y, Idt, T(0));                            // Y' = L^-1 as a tile
-            if (LDSST) sLM[k * LMR + 64 + r] = Zt; else lmk[TLM_Z + r] = Zt;
-            if (IPMV) {              // 1 / d_a for the corrector's solves (lanes (a, c != 0) store the same value to a spare slot)
-                const int rs = ta + (tc == 0 ? 0 : 4);
-                if (LDSST) sLM[k * LMR + 80 + rs] = ra; else lmk[TLM_RINV + rs] = ra;
-            }
+                });
+            riccati_factor_stage<PINS, IPMV, LAST, true>(SL, sh, sHg, r, Aq0, Aq1b, Bt, sin, pol, true, Pt, gm, ok, nanp, so, sink);
             if (!LAST) {
-                T Mn[4];
-                NMPC_UNROLL for (int t = 0; t < 4; t++) Mn[t] = -M0[t];
-                // Pbar is kept EXACTLY symmetric: products for the tiles on and above the diagonal, the diagonal tiles
-                // averaged with their transposes, the tiles below as transposes (X' I transposes a tile).  Computed
-                // independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
-                // contracted by the recursion: it grows by rho(A)^2 per stage - harmless for the reference's vehicle
-                // (rho = 1.04), a NaN after ~30 stages where the discretised open loop is violently unstable (dt = 0.1 with
-                // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The row form, the
-                // lane kernel and the oracle carry one triangle of P only.
-                NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                    NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44(Mn[it], M[jt], Pn[it][jt]);
-                }
-                NMPC_UNROLL for (int it = 0; it < 4; it++) Pt[it][it] = T(0.5) * (Pt[it][it] + mfma44(Pt[it][it], Idt, T(0)));
-                NMPC_UNROLL for (int it = 1; it < 4; it++) {
-                    NMPC_UNROLL for (int jt = 0; jt < it; jt++) Pt[it][jt] = mfma44(Pt[jt][it], Idt, T(0));
-                }
                 if (!IPMV && tP && k <= wnd) {
                     T *cp = tP + (size_t)k * TP_ROWS + r;
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
@@ -733,7 +575,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);   // tile (3,0) of Abar is zero
             const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
                       + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
-            const T ut = -mfma44(o.z, v, T(0));                           // lane (a,0): u_a
+            const T ut = mfma44_na(o.z, v, T(0));                         // lane (a,0): u_a = -(L^-T v)_a
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
             if constexpr (IPMV) {
                 // affine-scaling target of input a in lane (a,0): step-length terms of the predictor, target kept for the corrector
@@ -1054,7 +896,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(AT3z[it], xt[3], it < 3 ? mfma44(AT2[it], xt[2], xn[it]) : xn[it]);
             const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
                       + mfma44(o.mt[3], xt[3] + one15, mfma44(o.mt[1], xt[1], T(0)));
-            const T ut = -mfma44(o.z, v, T(0));
+            const T ut = mfma44_na(o.z, v, T(0));
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
             {
                 const Pair<T> pr(o.u, o.ll, o.lu, lb_a - o.ul, ub_a - o.ul);

@@ -56,7 +56,8 @@ def test_oracle_matches_acados_and_names_the_convention():
     table = {}
     for lm_dt in (1, 0):
         for cost_dt in (1, 0):
-            c = O.default_config(qp_gamma=0.0, qp_polish=1, lm_scaled_by_dt=lm_dt, cost_scaled_by_dt=cost_dt)
+            # (the accuracy certificate is behaviour HPIPM does not have: off when statuses are compared with acados)
+            c = O.default_config(qp_gamma=0.0, qp_polish=1, lm_scaled_by_dt=lm_dt, cost_scaled_by_dt=cost_dt, qp_growth_max=0.0)
             r = O.solve_batch(c, g["x0"], g["yref"], g["yref_e"])
             table[(lm_dt, cost_dt)] = _rel_err(r["u0"][ok], g["u0"][ok])
     best = min(table, key=table.get)
@@ -79,7 +80,7 @@ def test_hip_path_matches_acados():
     from rotors_mpc_controller_amd import _lib
     from rotors_mpc_controller_amd.solver import NmpcOcpSolver
     g, ok = _load()
-    s = NmpcOcpSolver(_lib.default_config(max_batch=int(g["x0"].shape[0])))
+    s = NmpcOcpSolver(_lib.default_config(max_batch=int(g["x0"].shape[0]), qp_growth_max=0.0))     # certificate off: see above
     out = s.solve_batch(g["x0"], g["yref"], g["yref_e"], want_traj=True)
     np.testing.assert_array_equal(out["status"][ok], 0)
     assert _rel_err(out["u0"][ok], g["u0"][ok]) <= 1e-6

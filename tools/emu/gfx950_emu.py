@@ -158,9 +158,13 @@ def parse_kernel(path: str, kernel_substr: str | None = None):
             continue
         if s.startswith("."):
             continue
+        ops, mods = [], {}
+        mneg = re.search(r"\s+neg:\[(\d),(\d),(\d)\]", s)        # MFMA f64: negate A | B | C
+        if mneg:
+            mods["neg"] = tuple(int(x) for x in mneg.groups())
+            s = s[:mneg.start()] + s[mneg.end():]
         parts = s.split(None, 1)
         op = parts[0]
-        ops, mods = [], {}
         if len(parts) > 1:
             for tok in parts[1].split(","):
                 tok = tok.strip()
@@ -945,6 +949,11 @@ def _v_mfma_f64_4x4x4(w, ins):
     X = _f64(w.rv64(xa)) if xa.kind in "va" else w.rf64(xa)
     Y = _f64(w.rv64(yb)) if yb.kind in "va" else w.rf64(yb)
     C = w.rf64(cc)
+    ng = ins.mods.get("neg")
+    if ng:
+        if ng[0]: X = -X
+        if ng[1]: Y = -Y
+        if ng[2]: C = -C
     out = np.zeros(64, dtype=np.float64)
     ld = np.longdouble
     for b in range(4):
