@@ -68,8 +68,44 @@ def _physical_cores(allowed) -> int:
     return len(seen)
 
 
+def _cgroup_cpu_quota() -> float:
+    """CPUs the container's cgroup grants (cpu.max / cfs quota), or 0.0 when there is no quota file or no limit."""
+    try:
+        f = Path("/sys/fs/cgroup/cpu.max")
+        if f.exists():
+            q, per = f.read_text().split()[:2]
+            return 0.0 if q == "max" else float(q) / float(per)
+        q = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read_text())
+        per = float(Path("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read_text())
+        return q / per if q > 0 else 0.0
+    except Exception:
+        return 0.0
+
+
+def _best_thread_count(solve, make_x0, allowed: int):
+    """The thread count that gives the highest rate on THIS box.  sched_getaffinity names every hardware thread of the host, but a GPU box
+    gives one job a share of them (round 4: 256 threads visible, the rate of 256 OpenMP threads 5.6x one thread): a quota in the cgroup
+    files is honoured if there is one, and the candidates (8, 16, 32, ... up to what is allowed) are measured on a short sample either way -
+    `cores` of the baseline is then the number of threads actually used, as the contract asks."""
+    quota = _cgroup_cpu_quota()
+    top = allowed if quota <= 0 else max(1, min(allowed, int(round(quota))))
+    cands = sorted({c for c in (4, 8, 16, 32, 64, 128, 256, top) if c <= top})
+    x = make_x0(max(2048, 16 * top))
+    best, table = cands[0], {}
+    for c in cands:
+        n = min(len(x), 128 * c)
+        for _ in range(2):
+            solve(x[:n], c)                                          # the OpenMP team of that size up and settled (the first regions after a resize are slow)
+        table[c] = 0.0
+        for _ in range(2):                                           # best of two
+            t = time.perf_counter(); solve(x[:n], c); table[c] = max(table[c], n / (time.perf_counter() - t))
+        if table[c] > table[best]:
+            best = c
+    return best, table, quota
+
+
 def _timed_all_cores(solve, make_x0, cores: int, floor: int, target_s: float = 2.5, cap: int = 1 << 20):
-    """Rate of `solve` over all hardware threads on a sample sized to ~target_s of wall time (never below `floor` = 64 x
+    """Rate of `solve` over `cores` threads on a sample sized to ~target_s of wall time (never below `floor` = 64 x
     threads: every thread gets a run of instances long enough that scheduling and the first touch of its workspace do not
     show).  Pass 1 (floor-sized) warms the thread pool and calibrates, pass 2 warms the sized sample, pass 3 is timed."""
     x = make_x0(floor)
@@ -97,37 +133,40 @@ def cpu_baseline(B_sample: int, N: int):
     yref, ye = O.hover_yref(c)
     x0 = sample_x0(B_sample, 0, **NEAR_HOVER)
     allowed = sorted(os.sched_getaffinity(0))
-    cores = len(allowed)
     phys = _physical_cores(allowed)
-    out = O.solve_batch(c, x0, yref, ye, nthreads=cores)      # the parity sample (also warms the pool)
+    out = O.solve_batch(c, x0, yref, ye, nthreads=min(len(allowed), 16))      # the parity sample
     mk = lambda n: sample_x0(n, 0, **NEAR_HOVER)
-    rate, n_all, _ = _timed_all_cores(lambda x, nt: O.solve_batch(c, x, yref, ye, nthreads=nt), mk, cores, max(64 * cores, 4096))
+    osolve = lambda x, nt: O.solve_batch(c, x, yref, ye, nthreads=nt)
+    cores, ctab, quota = _best_thread_count(osolve, mk, len(allowed))
+    rate, n_all, _ = _timed_all_cores(osolve, mk, cores, max(64 * cores, 4096))
     n1 = 4096
     x1 = mk(n1)
     O.solve_batch(c, x1[:256], yref, ye, nthreads=1)
     t = time.perf_counter()
     O.solve_batch(c, x1, yref, ye, nthreads=1)
     r1 = n1 / (time.perf_counter() - t)
-    smt = f"{cores} hardware threads on {phys} physical cores" if phys and phys != cores else f"{cores} cores"
-    row = dict(value=rate, unit="solves/s", cores=cores, physical_cores=phys or None, kind="port",
+    share = (f"{len(allowed)} hardware threads visible ({phys} physical cores)" + (f", cgroup quota {quota:.1f} CPUs" if quota > 0 else ", no cgroup quota readable")
+             + f"; thread count chosen by measurement {({k: round(v) for k, v in ctab.items()})}")
+    row = dict(value=rate, unit="solves/s", cores=cores, visible_hardware_threads=len(allowed), physical_cores=phys or None, kind="port",
                sample=f"{n_all} near-hover instances (config-2 recipe, seed 0), OpenMP static schedule over instances, "
                       f"oracle/nmpc_oracle.c (dense restatement, not acados/HPIPM); third of three passes",
                single_thread_value=r1, scaling_efficiency=rate / (cores * r1),
-               note=f"{smt}; efficiency is against hardware threads (two SMT threads share one core's FP64 units: "
-                    f"~0.5-0.6 is then the ceiling)")
+               note=f"{share}; scaling_efficiency = value / (cores x single-thread value) with cores = the threads used")
     try:
         from tests import hostsim as H
         cfg = _lib.default_config(N=N, flags=_lib.FLAG_SHARE_COLD_START)
         yr, yre = hover_reference(N, cfg.mass * cfg.gravity / 4.0)
-        chk = H.solve_batch(cfg, x0, yr, yre, nthreads=cores)            # the check: the oracle's own parity sample
-        rs, ns_all, hs = _timed_all_cores(lambda x, nt: H.solve_batch(cfg, x, yr, yre, nthreads=nt), mk, cores, max(64 * cores, 4096))
+        hsolve = lambda x, nt: H.solve_batch(cfg, x, yr, yre, nthreads=nt)
+        chk = hsolve(x0, min(len(allowed), 16))                          # the check: the oracle's own parity sample
+        scores, stab, _ = _best_thread_count(hsolve, mk, len(allowed))
+        rs, ns_all, hs = _timed_all_cores(hsolve, mk, scores, max(64 * scores, 4096))
         H.solve_batch(cfg, x1[:256], yr, yre, nthreads=1)
         t = time.perf_counter()
         H.solve_batch(cfg, x1, yr, yre, nthreads=1)
         rs1 = n1 / (time.perf_counter() - t)
         ok = (chk["status"] == 0) & (out["status"] == 0)
-        row["structured"] = dict(value=rs, unit="solves/s", cores=cores, physical_cores=phys or None, kind="port", single_thread_value=rs1,
-                                 scaling_efficiency=rs / (cores * rs1),
+        row["structured"] = dict(value=rs, unit="solves/s", cores=scores, physical_cores=phys or None, kind="port", single_thread_value=rs1,
+                                 scaling_efficiency=rs / (scores * rs1), thread_count_table={k: round(v) for k, v in stab.items()},
                                  sample=f"{ns_all} near-hover instances (config-2 recipe, seed 0), OpenMP static schedule over chunks of 8 lanes in "
                                         f"thread-private workspaces, host build of the lane kernel bodies nmpc_lane.hpp / nmpc_ipm.hpp "
                                         f"(tests/hostsim): structured Riccati, plain interior point; third of three passes",

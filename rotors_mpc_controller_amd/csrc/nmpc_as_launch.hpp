@@ -32,5 +32,8 @@ int launch_team_as(const AsLaunch &a, const Inputs<float> &in, const Outputs<flo
 // enqueue a kernel of nmpc_qp.hip: k_team_as (kind 0), k_team_qp (1), k_team_qp_list (2)
 int launch_team_qp(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
 int launch_team_qp(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
+// k_team_qp (kind 1) of nmpc_qpf.hip: the same source built with -amdgpu-mfma-vgpr-form
+int launch_team_qp_flag(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
+int launch_team_qp_flag(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
 
 }  // namespace nmpc

@@ -1,5 +1,9 @@
 // nmpc_block.hip -- kernels of the parallel-in-time Riccati factorisation (nmpc_block.hpp), default code generation.
+// (nmpc_blockf.hip includes this file to build the same kernels with -amdgpu-mfma-vgpr-form under another launcher name.)
 #include <hip/hip_runtime.h>
+#ifndef NMPC_BLOCK_EXPORT
+#define NMPC_BLOCK_EXPORT launch_block_factor
+#endif
 
 #include "nmpc_block_launch.hpp"
 
@@ -107,6 +111,6 @@ int launch_impl(const BlockLaunch &a, const Inputs<TI> &in)
 }  // namespace
 
 namespace nmpc {
-int launch_block_factor(const BlockLaunch &a, const Inputs<double> &in) { return launch_impl<double>(a, in); }
-int launch_block_factor(const BlockLaunch &a, const Inputs<float> &in) { return launch_impl<float>(a, in); }
+int NMPC_BLOCK_EXPORT(const BlockLaunch &a, const Inputs<double> &in) { return launch_impl<double>(a, in); }
+int NMPC_BLOCK_EXPORT(const BlockLaunch &a, const Inputs<float> &in) { return launch_impl<float>(a, in); }
 }  // namespace nmpc

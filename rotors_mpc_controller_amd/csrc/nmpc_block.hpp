@@ -186,11 +186,20 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     NMPC_UNROLL for (int t = 0; t < 4; t++) { SL.natR[t] = natR[t]; SL.Qdg[t] = Qdg[t]; SL.iq_col[t] = iq_col[t]; SL.iq_row[t] = iq_row[t]; }
     auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
     auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
-    T pfs[12];
-    auto fetch_stage = [&](int kq) {
-        const int k = shared ? 0 : kq;
+    // operands of a stage - its 11 stored tiles and 8 to 11 scalars - arrive TWO stages ahead in two alternating register sets: a block
+    // sweep runs on a few waves (the tail's lists are short), its stage is shorter than an HBM round trip, and one stage ahead left part of
+    // every load exposed (2.5 us per stage against 1.45 us for the same stage in the solver's sweep, whose tiles sit in LDS)
+    struct StOps { T pfs[12], yx, yu, xl, ul, pc, pca, ulc, u, ll, lu; };
+    auto fetch_ops = [&](int kq, StOps &o) {
+        const int kc = kq > s ? kq : s;                     // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
+        const int k = shared ? 0 : kc;
         const T *a = tAB + (size_t)k * TAB_ROWS + r;
-        NMPC_UNROLL for (int t = 0; t < 12; t++) pfs[t] = (t == 9) ? T(0) : a[t * 16];      // tile (3,0) is zero and never stored
+        NMPC_UNROLL for (int t = 0; t < 12; t++) o.pfs[t] = (t == 9) ? T(0) : a[t * 16];      // tile (3,0) is zero and never stored
+        o.yx = (T)yr[(size_t)kc * NY + rr]; o.yu = (T)yr[(size_t)kc * NY + NX + ta];
+        o.xl = xlin(kc); o.ul = ulin(kc, ta);
+        o.pc = tIV[kc * IV_ROWS + 16 + j]; o.pca = tIV[kc * IV_ROWS + 16 + ta]; o.ulc = ulin(kc, j);
+        o.u = 0; o.ll = 0; o.lu = 0;                        // the iterate of input a (interior-point iteration)
+        if (TAIL) { const T *ivn = tIV + kc * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; }
     };
 
     T Pt[4][4];
@@ -229,30 +238,22 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
         }
     }
     bool ok = true;
-    int ks = e - 1;
-    fetch_stage(ks);
-    T n_yx = (T)yr[(size_t)ks * NY + rr], n_yu = (T)yr[(size_t)ks * NY + NX + ta];
-    T n_xl = xlin(ks), n_ul = ulin(ks, ta);
-    T n_pc = tIV[ks * IV_ROWS + 16 + j], n_pca = tIV[ks * IV_ROWS + 16 + ta], n_ulc = ulin(ks, j);
-    T n_u = 0, n_ll = 0, n_lu = 0;                       // the iterate of input a (interior-point iteration)
-    if (TAIL) { n_u = tIV[ks * IV_ROWS + ta]; n_ll = tIV[ks * IV_ROWS + 4 + ta]; n_lu = tIV[ks * IV_ROWS + 8 + ta]; }
+    const int ks = e - 1;
+    StOps oa, ob;
+    fetch_ops(ks, oa);
+    fetch_ops(ks - 1, ob);
     T gm = 0;
     bool nanp = false;
-    for (int k = ks; k >= s; k--) {
+    auto stage = [&](int k, StOps &o) {
         T Aq0[4], Aq1b[4], Bt[4];
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
-        const int kn = k > s ? k - 1 : s;                   // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
-        fetch_stage(kn);
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = o.pfs[kt * 3]; Aq1b[kt] = o.pfs[kt * 3 + 1]; Bt[kt] = o.pfs[kt * 3 + 2]; }
         StageIn sin;
-        sin.ul = n_ul; sin.pc = n_pc; sin.pca = n_pca; sin.ulc = n_ulc; sin.u_it = n_u; sin.ll_it = n_ll; sin.lu_it = n_lu;
-        T rk = Wr_a * (sin.ul - n_yu);
-        sin.q_r = Wq_r * (n_xl - n_yx);
+        sin.ul = o.ul; sin.pc = o.pc; sin.pca = o.pca; sin.ulc = o.ulc; sin.u_it = o.u; sin.ll_it = o.ll; sin.lu_it = o.lu;
+        T rk = Wr_a * (sin.ul - o.yu);
+        sin.q_r = Wq_r * (o.xl - o.yx);
         asm volatile("" : "+v"(rk));
         sin.rk = rk;
-        n_yx = (T)yr[(size_t)kn * NY + rr]; n_yu = (T)yr[(size_t)kn * NY + NX + ta];
-        n_xl = xlin(kn); n_ul = ulin(kn, ta);
-        n_pc = tIV[kn * IV_ROWS + 16 + j]; n_pca = tIV[kn * IV_ROWS + 16 + ta]; n_ulc = ulin(kn, j);
-        if (TAIL) { const T *ivn = tIV + kn * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
+        fetch_ops(k - 2, o);                                // this set is free again: the stage two below
         // the stage: nmpc_stage.hpp, the source the solver's own backward sweep uses (pins variant; in tail mode the barrier terms of an
         // interior-point iteration instead, chosen per team by its tail state)
         StageOut so;
@@ -301,6 +302,10 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
             }
         }
         NMPC_WSYNC();
+    };
+    for (int k = ks; k >= s; k -= 2) {
+        stage(k, oa);
+        if (k - 1 >= s) stage(k - 1, ob);
     }
     if constexpr (AGG) {
         NMPC_UNROLL for (int it = 0; it < 4; it++) Cm[it][it] = T(0.5) * (Cm[it][it] + mfma44(Cm[it][it], Idt, T(0)));
@@ -389,9 +394,32 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Pe[it][jt] = bp[(it * 4 + jt) * 16];
         }
     }
+    // the aggregate of a boundary (J | Psi' | C: 42 tiles of 16 doubles from HBM) is fetched ONE BOUNDARY AHEAD: a boundary is a chain of
+    // dependent small factorisations with nothing to hide a 2 us load behind, and sixteen of them in sequence are the latency floor of a
+    // tail step
+    T nCf[4][4], nPs[4][4], nJt[10];
+    auto fetch_agg = [&](int b, T (&Cf_)[4][4], T (&Ps_)[4][4], T (&Jt_)[10]) {
+        const T *ap_ = g.agg + (winst * g.J + b) * 3 * BLK_MAT;
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) {
+                Cf_[it][jt] = ap_[2 * BLK_MAT + (it * 4 + jt) * 16 + r];
+                Ps_[it][jt] = ap_[BLK_MAT + (jt * 4 + it) * 16 + rT];          // Psi = Phi' through the transposed lane index
+            }
+        }
+        int q = 0;
+        NMPC_UNROLL for (int k = 0; k < 4; k++) {
+            NMPC_UNROLL for (int l = k; l < 4; l++) Jt_[q++] = ap_[(k * 4 + l) * 16 + r];
+        }
+    };
+    if (g.J >= 2) fetch_agg(g.J - 2, nCf, nPs, nJt);
     for (int blk = g.J - 2; blk >= 0; blk--) {
-        const T *ap = g.agg + (winst * g.J + blk) * 3 * BLK_MAT;
         bool ok = true;
+        T Cf[4][4], Ps[4][4], Jt[10];
+        NMPC_UNROLL for (int it = 0; it < 4; it++) {
+            NMPC_UNROLL for (int jt = 0; jt < 4; jt++) { Cf[it][jt] = nCf[it][jt]; Ps[it][jt] = nPs[it][jt]; }
+        }
+        NMPC_UNROLL for (int q = 0; q < 10; q++) Jt[q] = nJt[q];
+        fetch_agg(blk > 0 ? blk - 1 : 0, nCf, nPs, nJt);            // clamped, not skipped
         // P_e with unit pads (positions 3 and 7 of the padded state carry nothing) = L Dp L', the constant's pivot forced to 1
         T Au[4][4];
         NMPC_UNROLL for (int it = 0; it < 4; it++) {
@@ -408,10 +436,6 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
         // E = Dp^-1 + L' C L (upper tiles): F = C L, E = L' F
         T E[4][4];
         {
-            T Cf[4][4];
-            NMPC_UNROLL for (int it = 0; it < 4; it++) {
-                NMPC_UNROLL for (int jt = 0; jt < 4; jt++) Cf[it][jt] = ap[2 * BLK_MAT + (it * 4 + jt) * 16 + r];
-            }
             T F[4][4];
             NMPC_UNROLL for (int i = 0; i < 4; i++) {
                 NMPC_UNROLL for (int k = 0; k < 4; k++) {
@@ -435,10 +459,6 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
         // Z = Le^-1 (L' Psi), rows of tiles by forward substitution; Psi = Phi' is read through the transposed lane index
         T Z[4][4];
         {
-            T Ps[4][4];
-            NMPC_UNROLL for (int n = 0; n < 4; n++) {
-                NMPC_UNROLL for (int k = 0; k < 4; k++) Ps[n][k] = ap[BLK_MAT + (k * 4 + n) * 16 + rT];
-            }
             NMPC_UNROLL for (int i = 0; i < 4; i++) {
                 NMPC_UNROLL for (int k = 0; k < 4; k++) {
                     T a = 0;
@@ -464,11 +484,14 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
             NMPC_UNROLL for (int k = 0; k < 4; k++) gp[(q++) * 16] = le.ra[k];
         }
         // P_s = J + Z' De^-1 Z
-        NMPC_UNROLL for (int k = 0; k < 4; k++) {
-            NMPC_UNROLL for (int l = k; l < 4; l++) {
-                T a = ap[(k * 4 + l) * 16 + r];
-                NMPC_UNROLL for (int i = 0; i < 4; i++) a = mfma44(Z[i][k], le.ra[i] * Z[i][l], a);
-                Pe[k][l] = a;
+        {
+            int q = 0;
+            NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                NMPC_UNROLL for (int l = k; l < 4; l++) {
+                    T a = Jt[q++];
+                    NMPC_UNROLL for (int i = 0; i < 4; i++) a = mfma44(Z[i][k], le.ra[i] * Z[i][l], a);
+                    Pe[k][l] = a;
+                }
             }
         }
         NMPC_UNROLL for (int it = 0; it < 4; it++) Pe[it][it] = T(0.5) * (Pe[it][it] + mfma44(Pe[it][it], Idt, T(0)));
@@ -489,43 +512,67 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
         T xt[4];
         NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
         T *xp = g.xb + winst * g.J * 16;
+        // tile index of L[m][k] (m >= k), of Le'[k][m] (m > k), of Le_kk^-T, of 1 / de in the boundary's slot
+        auto iL = [](int m, int k) { return (k == 0 ? 0 : (k == 1 ? 4 : (k == 2 ? 7 : 9))) + (m - k); };
+        auto iE = [](int k, int m) { return 10 + (k == 0 ? 0 : (k == 1 ? 3 : 5)) + (m - k - 1); };
+        // the 76 operand tiles of a boundary, every one in the orientation its product needs (a transposed tile is the same 16 doubles
+        // through the swapped lane index), fetched ONE BOUNDARY AHEAD: the walk is a chain of six dependent matrix-vector products per
+        // boundary with nothing to hide a load behind (2.7 us per boundary when the loads sat inside the chain)
+        struct FwOps { T P1[4][4], L2[4][4], E3[4][4], Y3[4], Rd[4], E5[4][4], Y5[4], L6[4][4], C7[4][4]; };
+        auto fetch_fw = [&](int bq, FwOps &f) {
+            const int b = bq < g.J - 1 ? bq : (g.J >= 2 ? g.J - 2 : 0);          // clamped, not skipped
+            const T *ap = g.agg + (winst * g.J + b) * 3 * BLK_MAT;
+            const T *gp = g.gbuf + (winst * g.J + b) * BLK_GB;
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {
+                NMPC_UNROLL for (int k = 0; k < 4; k++) {
+                    f.P1[i][k] = ap[BLK_MAT + (k * 4 + i) * 16 + r];             // Psi[i][k]' = Phi[k][i] as stored
+                    f.C7[i][k] = ap[2 * BLK_MAT + (k * 4 + i) * 16 + r];         // C[k][i] (C symmetric)
+                    if (k >= i) f.L2[i][k] = gp[iL(k, i) * 16 + r];              // L[k][i]
+                    if (k < i) f.E3[i][k] = gp[iE(k, i) * 16 + r];               // Le'[k][i]
+                    if (k > i) f.E5[i][k] = gp[iE(i, k) * 16 + rT];              // (Le'[i][k])'
+                    if (k <= i) f.L6[i][k] = gp[iL(i, k) * 16 + rT];             // L[i][k]'
+                }
+                f.Y3[i] = gp[(16 + i) * 16 + r];
+                f.Y5[i] = gp[(16 + i) * 16 + rT];
+                f.Rd[i] = gp[(20 + i) * 16 + r];
+            }
+        };
+        FwOps fn;
+        if (g.J >= 2) fetch_fw(0, fn);
         for (int blk = 0; blk < g.J; blk++) {
             if (tc == 0) { NMPC_UNROLL for (int t = 0; t < 4; t++) xp[blk * 16 + t * 4 + ta] = xt[t]; }
             if (blk == g.J - 1) break;
-            const T *ap = g.agg + (winst * g.J + blk) * 3 * BLK_MAT;
-            const T *gp = g.gbuf + (winst * g.J + blk) * BLK_GB;
-            // tile index of L[m][k] (m >= k), of Le'[k][m] (m > k), of Le_kk^-T, of 1 / de in the boundary's slot
-            auto iL = [](int m, int k) { return (k == 0 ? 0 : (k == 1 ? 4 : (k == 2 ? 7 : 9))) + (m - k); };
-            auto iE = [](int k, int m) { return 10 + (k == 0 ? 0 : (k == 1 ? 3 : 5)) + (m - k - 1); };
+            const FwOps f = fn;
+            fetch_fw(blk + 1, fn);
             T y1[4], y2[4], y3[4], y5[4], y6[4];
-            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y1 = Psi x: a = Psi[i][k]' = Phi[k][i] as stored
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y1 = Psi x
                 T a = 0;
-                NMPC_UNROLL for (int k = 0; k < 4; k++) a = mfma44(ap[BLK_MAT + (k * 4 + i) * 16 + r], xt[k], a);
+                NMPC_UNROLL for (int k = 0; k < 4; k++) a = mfma44(f.P1[i][k], xt[k], a);
                 y1[i] = a;
             }
-            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y2 = L' y1: a = L[n][i]
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y2 = L' y1
                 T a = 0;
-                NMPC_UNROLL for (int n = i; n < 4; n++) a = mfma44(gp[iL(n, i) * 16 + r], y1[n], a);
+                NMPC_UNROLL for (int n = i; n < 4; n++) a = mfma44(f.L2[i][n], y1[n], a);
                 y2[i] = a;
             }
-            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y3 = Le^-1 y2 (forward substitution): a = Le'[m][i], Le_ii^-T
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y3 = Le^-1 y2 (forward substitution)
                 T a = y2[i];
-                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m < i) a = mfma44(-gp[iE(m, i) * 16 + r], y3[m], a); }
-                y3[i] = mfma44(gp[(16 + i) * 16 + r], a, T(0));
+                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m < i) a = mfma44_na(f.E3[i][m], y3[m], a); }
+                y3[i] = mfma44(f.Y3[i], a, T(0));
             }
-            NMPC_UNROLL for (int i = 3; i >= 0; i--) {            // y5 = Le^-T De^-1 y3 (back substitution): a = (Le'[i][m])' , (Le_ii^-T)'
-                T a = gp[(20 + i) * 16 + r] * y3[i];
-                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m > i) a = mfma44(-gp[iE(i, m) * 16 + rT], y5[m], a); }
-                y5[i] = mfma44(gp[(16 + i) * 16 + rT], a, T(0));
+            NMPC_UNROLL for (int i = 3; i >= 0; i--) {            // y5 = Le^-T De^-1 y3 (back substitution)
+                T a = f.Rd[i] * y3[i];
+                NMPC_UNROLL for (int m = 0; m < 4; m++) { if (m > i) a = mfma44_na(f.E5[i][m], y5[m], a); }
+                y5[i] = mfma44(f.Y5[i], a, T(0));
             }
-            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y6 = L y5: a = L[i][m]'
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // y6 = L y5
                 T a = 0;
-                NMPC_UNROLL for (int m = 0; m <= i; m++) a = mfma44(gp[iL(i, m) * 16 + rT], y5[m], a);
+                NMPC_UNROLL for (int m = 0; m <= i; m++) a = mfma44(f.L6[i][m], y5[m], a);
                 y6[i] = a;
             }
-            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // x_e = y1 - C y6: a = C[m][i] (C symmetric)
+            NMPC_UNROLL for (int i = 0; i < 4; i++) {             // x_e = y1 - C y6
                 T a = y1[i];
-                NMPC_UNROLL for (int m = 0; m < 4; m++) a = mfma44(-ap[2 * BLK_MAT + (m * 4 + i) * 16 + r], y6[m], a);
+                NMPC_UNROLL for (int m = 0; m < 4; m++) a = mfma44_na(f.C7[i][m], y6[m], a);
                 xt[i] = a;
             }
         }

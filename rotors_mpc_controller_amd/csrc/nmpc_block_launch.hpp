@@ -20,5 +20,8 @@ struct BlockLaunch {
 // enqueue the factorisation (J = 1: one ordinary sweep per instance, the sequential form in the same code); returns a hipError_t
 int launch_block_factor(const BlockLaunch &a, const Inputs<double> &in);
 int launch_block_factor(const BlockLaunch &a, const Inputs<float> &in);
+// ... the same kernels from nmpc_blockf.hip (built with -amdgpu-mfma-vgpr-form)
+int launch_block_factor_flag(const BlockLaunch &a, const Inputs<double> &in);
+int launch_block_factor_flag(const BlockLaunch &a, const Inputs<float> &in);
 
 }  // namespace nmpc

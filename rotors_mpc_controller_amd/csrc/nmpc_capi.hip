@@ -120,6 +120,8 @@ struct nmpc_solver {
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
+    int block_noflag = 0;            // NMPC_BLOCK_NOFLAG=1: block kernels from nmpc_block.hip (default code generation) instead of nmpc_blockf.hip
+    int qp_noflag = 0;               // NMPC_QP_NOFLAG=1: k_team_qp from nmpc_qp.hip (default code generation) instead of nmpc_qpf.hip
     int as_v256 = 0;                 // NMPC_AS_BUILD=v256: the 256-register build with the LDS stage cache (nmpc_qp.hip, OCC = 3)
     int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
@@ -393,6 +395,8 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_BLOCK_NOFLAG")) s->block_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_BUILD")) {
         s->as_v256 = std::strcmp(e, "v256") == 0;
         if (std::strcmp(e, "default") == 0) s->as_noflag = 1;
@@ -624,7 +628,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
                 bl.g.list = lists[cur].list; bl.g.count = lists[cur].count; bl.g.reset_count = nullptr;
                 // the list this step appends to was consumed by the previous step: its count is zeroed between the two block sweeps
                 bl.g.reset_count = lists[cur ^ 1].count;
-                HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+                HIP_TRY(s, (hipError_t)(s->block_noflag ? launch_block_factor(bl, in) : launch_block_factor_flag(bl, in)));
             }
             tl.tail.frec = nullptr;
             if (phase == 2 && s->tail_fwd) {
@@ -778,7 +782,9 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                 al.occ = 1; al.shared = c.shared != 0; al.traj = out.x_out != nullptr || out.u_out != nullptr;
                 al.stream = st; al.kind = 1;
                 qp_lds(s, c.shared != 0, al);
-                HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
+                // the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator steps, as k_team_as - else the default one
+                if (s->cfg.sim_num_steps <= 2 && !s->qp_noflag) HIP_TRY(s, (hipError_t)launch_team_qp_flag(al, in, out));
+                else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
                 if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
                 s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
                 s->last_shared = c.shared != 0;
@@ -1233,12 +1239,12 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
         Inputs<float> in;
         in.x0 = (const float *)x0; in.yref = (const float *)yref; in.yref_e = (const float *)yref_e;
         in.x_init = (const float *)x_init; in.u_init = (const float *)u_init; in.yref_bcast = yref_bcast;
-        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+        HIP_TRY(s, (hipError_t)(s->block_noflag ? launch_block_factor(bl, in) : launch_block_factor_flag(bl, in)));
     } else {
         Inputs<double> in;
         in.x0 = (const double *)x0; in.yref = (const double *)yref; in.yref_e = (const double *)yref_e;
         in.x_init = (const double *)x_init; in.u_init = (const double *)u_init; in.yref_bcast = yref_bcast;
-        HIP_TRY(s, (hipError_t)launch_block_factor(bl, in));
+        HIP_TRY(s, (hipError_t)(s->block_noflag ? launch_block_factor(bl, in) : launch_block_factor_flag(bl, in)));
     }
     if (factors_out) HIP_TRY(s, hipMemcpyAsync(factors_out, s->blk_fac, (size_t)B * N * BLK_FAC_ROWS * sizeof(double), hipMemcpyDeviceToDevice, st));
     // boundary_out / check_out are the CALLER's [B][blocks + 1][256]: rows 0 .. Jeff of every instance are written (Jeff <= blocks is only

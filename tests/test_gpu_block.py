@@ -195,3 +195,38 @@ def test_tail_is_the_default_from_horizon_160_and_handles_fp32_buffers(monkeypat
     np.testing.assert_array_equal(ita, itb)
     np.testing.assert_allclose(b["u0"], a["u0"], rtol=0, atol=2e-6)          # FP32 outputs: one ulp of a 6 N command is 5e-7
     np.testing.assert_allclose(b["x"], a["x"], rtol=0, atol=2e-5)
+
+
+def test_flag_build_of_the_block_kernels_is_bit_equal_to_the_default_codegen_build(monkeypatch):
+    """The block kernels (k_block_sweep, k_block_scan and their tail forms) exist twice since round 4: nmpc_blockf.hip built with
+    -mllvm -amdgpu-mfma-vgpr-form (what runs), nmpc_block.hip with the default code generation (NMPC_BLOCK_NOFLAG=1).  Same source, same
+    arithmetic: a long-horizon solve through the tail and the factorisation building block must agree bit for bit."""
+    import torch
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    N, B = 600, 256
+    yref, ye = hover_reference(N, 0.68 * 9.81 / 4.0)
+    x0 = sample_x0(B, 5, **NEAR_HOVER)
+    res = []
+    for noflag in ("0", "1"):
+        monkeypatch.setenv("NMPC_BLOCK_NOFLAG", noflag)
+        s = NmpcOcpSolver(_lib.default_config(N=N, max_batch=B))
+        out = s.solve_batch(x0, yref, ye, want_traj=True)
+        it, ps = s.counts()
+        blocks, states = s.tail_states(B)
+        # the building block on the per-stage tiles of a warm-started solve
+        out2 = s.solve_batch(x0, yref, ye, x_init=out["x"], u_init=out["u"], want_traj=True)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+        d = [dev(x0), dev(yref), dev(ye), dev(out["x"]), dev(out["u"])]
+        fac = torch.zeros(B, N, 80, dtype=torch.float64, device="cuda")
+        Jeff, _ = s.block_factor_device(B, 17, d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), True, x_init_ptr=d[3].data_ptr(),
+                                        u_init_ptr=d[4].data_ptr(), factors_ptr=fac.data_ptr())
+        torch.cuda.synchronize()
+        res.append((out, it.copy(), ps.copy(), states.copy(), out2, fac.cpu().numpy(), blocks, Jeff))
+        s.close()
+    a, b = res
+    assert a[6] > 0 and (a[3] == 3).sum() > 0 and a[7] == b[7]          # the tail ran and finished instances
+    for key in ("u0", "status", "x", "u"):
+        np.testing.assert_array_equal(a[0][key], b[0][key])
+        np.testing.assert_array_equal(a[4][key], b[4][key])
+    np.testing.assert_array_equal(a[1], b[1]); np.testing.assert_array_equal(a[2], b[2]); np.testing.assert_array_equal(a[3], b[3])
+    np.testing.assert_array_equal(a[5], b[5])

@@ -542,3 +542,30 @@ def test_three_and_four_integrator_steps_per_stage_linearisation_with_trajectori
         np.testing.assert_array_equal(it, r["iters"])
     assert s.guard_check() == 0
     s.close()
+
+
+@pytest.mark.parametrize("share", [1, 0])
+def test_flag_build_of_the_interior_point_kernel_is_bit_equal_to_the_default_codegen_build(share, monkeypatch):
+    """k_team_qp - the whole interior-point QP for the whole batch (qp_polish = 0, or an attempt schedule that starts with iterations) - is
+    built twice since round 4: nmpc_qpf.hip with -mllvm -amdgpu-mfma-vgpr-form (12 % fewer instructions: no accumulation-register moves),
+    nmpc_qp.hip with the default code generation (NMPC_QP_NOFLAG=1).  Same arithmetic, different register placement: every output bit and
+    every iteration count must agree - plain interior point and the single-kernel attempt schedule, cold and warm-started, trajectories."""
+    yref, ye = hover(_lib.default_config())
+    x0 = np.concatenate([sample_x0(200, 91, **NEAR_HOVER), sample_x0(200, 92, **AGGRESSIVE), sample_x0(111, 93, **WILD)])
+    for over in (dict(qp_polish=0), dict(qp_polish=1, qp_polish_mu=1e-2)):
+        res = []
+        for noflag in ("0", "1"):
+            monkeypatch.setenv("NMPC_QP_NOFLAG", noflag)
+            s = make_solver(flags=_lib.FLAG_TEAM_MAPPING | share, **over)
+            a = s.solve_batch(x0, yref, ye, want_traj=True)
+            ia = s.iterations()
+            b = s.solve_batch(x0, yref, ye, x_init=a["x"], u_init=a["u"], want_traj=True)
+            res.append((a, ia, b, s.iterations()))
+            s.close()
+        (a0, i0, b0, j0), (a1, i1, b1, j1) = res
+        for key in ("u0", "status", "x", "u"):
+            np.testing.assert_array_equal(a0[key], a1[key])
+            np.testing.assert_array_equal(b0[key], b1[key])
+        np.testing.assert_array_equal(i0, i1)
+        np.testing.assert_array_equal(j0, j1)
+        assert i0.max() >= 3                      # (interior-point iterations really ran)

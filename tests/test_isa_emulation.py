@@ -61,6 +61,13 @@ def test_shipped_flag_build_of_k_team_as_warm_started_per_stage_with_trajectorie
     _check(s, "k_team_asILb0ELb1ELi1EdEE", range(0, 2), steps=2, polish=1, share=1, B=2048, dist="aggressive", seed=1, kind="as", warm=True)
 
 
+def test_shipped_flag_build_of_the_interior_point_kernel():
+    """k_team_qp<shared, no trajectories, double> of nmpc_qpf.hip (what bench.py --no-polish and qp_polish = 0 run), plain interior point: two
+    workgroups of four instances through ~80 k instructions each."""
+    s = _asm("nmpc_qpf.s")
+    _check(s, "k_team_qpILb1ELb0EdEE", range(0, 2), steps=2, polish=0, share=1, B=2048, dist="near_hover", seed=0, kind="qp")
+
+
 @pytest.mark.skipif(os.environ.get("NMPC_EMU_FULL") != "1", reason="NMPC_EMU_FULL=1: compiles nmpc_qp.hip with the flag (minutes); profiles/r04_emulation_*.txt holds the full runs")
 def test_the_configuration_that_faulted_in_round_3_on_the_flag_build_of_k_team_qp():
     """k_team_qp<per-stage, trajectories>, sim_num_steps = 4, qp_polish = 0, B = 256, aggressive seed 8 (gpurun_out/qp_check2.log), built WITH
