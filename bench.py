@@ -583,6 +583,13 @@ def main() -> None:
     # (two more stream operations per step) are switched back on for one untimed step afterwards,
     # which yields the isolated kernel times and the iteration statistics
     solver.set_timing(args.per_solve_events)
+    # NMPC_BENCH_PREROLL=<n> (experiments, default 0): n untimed steps before the contract's W warmup steps - shows how much of a short run's
+    # step time is the GPU still ramping its clocks; the driver's runs use the default
+    preroll = int(os.environ.get("NMPC_BENCH_PREROLL", "0"))
+    for _ in range(preroll):
+        step()
+    if preroll:
+        fence()
     for _ in range(args.warmup):
         step()
     fence()
@@ -686,7 +693,7 @@ def main() -> None:
                                          f"{args.dtype.upper()}, cold start, hover yref {args.yref}",
                                 batch_per_gpu=B, horizon=N, share_cold_start=not args.no_share, mapping=args.mapping,
                                 device_buffers=("f32" if args.dtype != "f64" else "f64"),
-                                traj_out=args.traj_out, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks",
+                                traj_out=args.traj_out, preroll_steps=preroll, parallelism=f"batch-sharded x{world}, all-gather of u0 every {G} ticks",
                                 exchange=exchange),
                     ipm_iterations=dict(mean=st["iter_mean"], min=st["iter_min"], max=st["iter_max"]),
                     active_set_passes=dict(mean=st["polish_mean"], max=st["polish_max"], accepted=st["n_polished"]),

@@ -121,6 +121,7 @@ struct nmpc_solver {
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
     int block_noflag = 0;            // NMPC_BLOCK_NOFLAG=1: block kernels from nmpc_block.hip (default code generation) instead of nmpc_blockf.hip
+    int lds_overlap = 1;             // NMPC_LDS_OVERLAP=0: the per-stage variant's stage cache behind the evaluation-point buffer (round 3)
     int qp_noflag = 0;               // NMPC_QP_NOFLAG=1: k_team_qp from nmpc_qp.hip (default code generation) instead of nmpc_qpf.hip
     int as_v256 = 0;                 // NMPC_AS_BUILD=v256: the 256-register build with the LDS stage cache (nmpc_qp.hip, OCC = 3)
     int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
@@ -396,6 +397,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_LDS_OVERLAP")) s->lds_overlap = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_BLOCK_NOFLAG")) s->block_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_BUILD")) {
         s->as_v256 = std::strcmp(e, "v256") == 0;
@@ -529,16 +531,40 @@ static int as_lds_base(const nmpc_solver *s, bool shared)
     return shared ? TEAM_AS_LDS_SHARED + (s->cfg.sim_num_steps > 2 ? AS_EV : 0) : TEAM_AS_LDS_STAGE;
 }
 
+// Where a team's stage cache starts.  The evaluation-point buffer of the linearisation (per-stage variant: 448 of a team's 1280 doubles)
+// is dead once the preparation has run, so the cache of the per-stage variant starts AT it (A_EV) instead of behind it: five more stages
+// of factors stay in LDS (11 instead of 6 in k_team_as).  The shared variant's single stage of evaluation points is small and stays.
+// NMPC_LDS_OVERLAP=0 restores the round-3 placement.
+// the kernels that iterate the interior point method: the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator
+// steps, as k_team_as - else (and with NMPC_QP_NOFLAG=1) the default code generation (nmpc_qp.hip)
+template <class TI>
+static int launch_qp_kind(const nmpc_solver *s, const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
+{
+    if (a.kind >= 1 && a.kind <= 3 && s->cfg.sim_num_steps <= 2 && !s->qp_noflag) return launch_team_qp_flag(a, in, out);
+    return launch_team_qp(a, in, out);
+}
+
+static int as_cache_base(const nmpc_solver *s, bool shared)
+{
+    return (shared || !s->lds_overlap) ? as_lds_base(s, shared) : A_EV;
+}
+// stride of a team's LDS (carve + cache), 192 B past a multiple of the 256-B bank row; at least the carve the preparation needs
+static int as_lds_stride(const nmpc_solver *s, bool shared, int lstg, int rows)
+{
+    int stride = std::max(as_lds_base(s, shared), as_cache_base(s, shared) + lstg * rows);
+    stride += (24 - stride % 32 + 32) % 32;
+    return stride;
+}
+
 // LDS carve of the kernels that iterate the interior point method (k_team_qp, k_team_qp_list: one wave per SIMD, 40 KB per wave):
-// stage cache rows of IP_LM_ROWS doubles, team stride 192 B past a multiple of the 256-B bank row
+// stage cache rows of IP_LM_ROWS doubles
 static void qp_lds(const nmpc_solver *s, bool shared, AsLaunch &a)
 {
-    const int base = as_lds_base(s, shared);
+    const int base = as_cache_base(s, shared);
     const int per_team = 40960 / 4 / (int)sizeof(double);
     int lstg = std::max(0, std::min(s->cfg.N, (per_team - base - 31) / IP_LM_ROWS));
     if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
-    int stride = base + lstg * IP_LM_ROWS;
-    stride += (24 - stride % 32 + 32) % 32;
+    const int stride = as_lds_stride(s, shared, lstg, IP_LM_ROWS);
     a.lstg = lstg; a.lds_stride = stride; a.lm_off = base; a.lds_bytes = (size_t)4 * stride * sizeof(double);
 }
 
@@ -566,12 +592,11 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD) holds the
     // factors of the first stages; the team stride stays 192 B past a multiple of the 256-B bank row (24 doubles mod 32).
     // The two-waves build carries no cache.
-    const int base_as = as_lds_base(s, c.shared != 0);
+    const int base_as = as_cache_base(s, c.shared != 0);
     const int per_team = 40960 / 4 / (int)sizeof(double);
     int lstg = occ_as == 2 ? 0 : std::max(0, std::min(s->cfg.N, (per_team - base_as - 31) / AS_LM_ROWS));
     if (s->team_lstg >= 0) lstg = std::min(lstg, s->team_lstg);
-    int lds_stride = base_as + lstg * AS_LM_ROWS;
-    lds_stride += (24 - lds_stride % 32 + 32) % 32;
+    const int lds_stride = as_lds_stride(s, c.shared != 0, lstg, AS_LM_ROWS);
     const size_t lds_as = (size_t)4 * lds_stride * sizeof(double);
     AsLaunch al;
     al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
@@ -635,10 +660,10 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
                 // forward sweep of the pass: the blocks of every instance at the same time (phase 3), then the decision (phase 2)
                 tl.tail.frec = s->tail_frec; tl.tail.xb = s->tail_xb; tl.tail.M = s->tail_M;
                 tl.tail.phase = 3;
-                HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+                HIP_TRY(s, (hipError_t)launch_qp_kind(s, tl, in, out));
                 tl.tail.phase = 2;
             }
-            HIP_TRY(s, (hipError_t)launch_team_qp(tl, in, out));
+            HIP_TRY(s, (hipError_t)launch_qp_kind(s, tl, in, out));
             cur ^= 1;
             return 0;
         };
@@ -651,7 +676,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1; ql.wl = wl2;
-        HIP_TRY(s, (hipError_t)launch_team_qp(ql, in, out));
+        HIP_TRY(s, (hipError_t)launch_qp_kind(s, ql, in, out));
         AsLaunch rl = al;
         rl.kind = 4; rl.tail.nx_count = lists[1].count;
         HIP_TRY(s, (hipError_t)launch_team_qp(rl, in, out));
@@ -659,7 +684,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1;
-        HIP_TRY(s, (hipError_t)launch_team_qp(ql, in, out));
+        HIP_TRY(s, (hipError_t)launch_qp_kind(s, ql, in, out));
     } else {
         if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
         else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
@@ -783,8 +808,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
                 al.stream = st; al.kind = 1;
                 qp_lds(s, c.shared != 0, al);
                 // the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator steps, as k_team_as - else the default one
-                if (s->cfg.sim_num_steps <= 2 && !s->qp_noflag) HIP_TRY(s, (hipError_t)launch_team_qp_flag(al, in, out));
-                else HIP_TRY(s, (hipError_t)launch_team_qp(al, in, out));
+                HIP_TRY(s, (hipError_t)launch_qp_kind(s, al, in, out));
                 if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
                 s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
                 s->last_shared = c.shared != 0;

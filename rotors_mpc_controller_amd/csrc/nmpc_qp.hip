@@ -14,9 +14,10 @@
 
 using namespace nmpc;
 
-// nmpc_qpf.hip includes this file with NMPC_QP_WHOLE_BATCH_ONLY to build ONE kernel of it - k_team_qp, the whole interior-point QP for the
-// whole batch - a second time with -amdgpu-mfma-vgpr-form (round 4: validated like k_team_as - bit-equal to this file's build on the GPU,
-// executed instruction by instruction by tools/emu); the exported launcher then has another name
+// nmpc_qpf.hip includes this file with NMPC_QP_WHOLE_BATCH_ONLY to build the kernels that iterate the interior point method - k_team_qp
+// (whole QP, whole batch), k_team_qp_list (work list), k_team_tail (long-horizon tail) - a second time with -amdgpu-mfma-vgpr-form
+// (round 4: validated like k_team_as - bit-equal to this file's builds on the GPU, k_team_qp executed instruction by instruction by
+// tools/emu); the exported launcher then has another name
 #ifndef NMPC_QP_EXPORT
 #define NMPC_QP_EXPORT launch_team_qp
 #endif
@@ -45,7 +46,7 @@ __global__ __launch_bounds__(64, OCC == 1 ? 1 : 2) void k_team_as(const Consts<d
     team_as<SHARED, TRAJ, OCC != 2, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, -2, tcx);
 }
 
-#endif  // !NMPC_QP_WHOLE_BATCH_ONLY
+#endif  // !NMPC_QP_WHOLE_BATCH_ONLY (k_team_as)
 
 // The whole QP of every instance of the batch in one launch (team_as MODE 1): interior-point iterations in the tile form,
 // active-set attempts in between when qp_polish is on.  What qp_polish = 0 runs, and NMPC_TEAM_SPLIT=0.  One wave per SIMD.
@@ -57,7 +58,6 @@ __global__ __launch_bounds__(64, 1) void k_team_qp(const Consts<double> *__restr
     team_as<SHARED, TRAJ, true, TI, 1>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off);
 }
 
-#ifndef NMPC_QP_WHOLE_BATCH_ONLY
 // Second launch of the default FP64 path (team_as MODE 2): the instances the active-set kernel appended to the work list -
 // usually none - continue where its first attempt ended: interior-point iterations, further attempts from the iterate's
 // active-set guess.  A fixed small grid strides over the list; the last workgroup to finish resets it for the next solve.
@@ -111,9 +111,9 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
     }
 }
 
+#ifndef NMPC_QP_WHOLE_BATCH_ONLY
 __global__ void k_list_reset(WorkList wl, int *second_count) { *wl.count = 0; *wl.done = 0; if (second_count) *second_count = 0; }
-
-#endif  // !NMPC_QP_WHOLE_BATCH_ONLY
+#endif
 
 template <class TI>
 int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
@@ -123,6 +123,7 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
         hipLaunchKernelGGL(k_list_reset, dim3(1), dim3(1), 0, a.stream, a.wl, a.tail.nx_count);
         return (int)hipGetLastError();
     }
+#endif
     if (a.kind == 3) {
         const dim3 grid(a.nlist, a.tail.phase == 3 ? a.tail.J : 1), block(64);
 #define NMPC_LAUNCH_TL(SH_, TR_) hipLaunchKernelGGL((k_team_tail<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.lds_stride, a.lm_off, a.tail)
@@ -131,7 +132,6 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 #undef NMPC_LAUNCH_TL
         return (int)hipGetLastError();
     }
-#endif
     if (a.kind == 1) {
         const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
 #define NMPC_LAUNCH_QP(SH_, TR_) hipLaunchKernelGGL((k_team_qp<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off)
@@ -140,9 +140,6 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 #undef NMPC_LAUNCH_QP
         return (int)hipGetLastError();
     }
-#ifdef NMPC_QP_WHOLE_BATCH_ONLY
-    return (int)hipErrorInvalidValue;
-#else
     if (a.kind == 2) {
         const dim3 grid(a.nlist), block(64);
 #define NMPC_LAUNCH_QL(SH_, TR_) hipLaunchKernelGGL((k_team_qp_list<SH_, TR_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.lds_stride, a.lstg, a.lm_off)
@@ -151,6 +148,9 @@ int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 #undef NMPC_LAUNCH_QL
         return (int)hipGetLastError();
     }
+#ifdef NMPC_QP_WHOLE_BATCH_ONLY
+    return (int)hipErrorInvalidValue;
+#else
     const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
 #define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off, a.tail.cap, a.tail.ts)
     if (a.shared) {

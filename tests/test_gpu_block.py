@@ -198,7 +198,7 @@ def test_tail_is_the_default_from_horizon_160_and_handles_fp32_buffers(monkeypat
 
 
 def test_flag_build_of_the_block_kernels_is_bit_equal_to_the_default_codegen_build(monkeypatch):
-    """The block kernels (k_block_sweep, k_block_scan and their tail forms) exist twice since round 4: nmpc_blockf.hip built with
+    """The block kernels (k_block_sweep, k_block_scan and their tail forms) and the tail's own kernel k_team_tail exist twice since round 4: nmpc_blockf.hip built with
     -mllvm -amdgpu-mfma-vgpr-form (what runs), nmpc_block.hip with the default code generation (NMPC_BLOCK_NOFLAG=1).  Same source, same
     arithmetic: a long-horizon solve through the tail and the factorisation building block must agree bit for bit."""
     import torch
@@ -209,6 +209,7 @@ def test_flag_build_of_the_block_kernels_is_bit_equal_to_the_default_codegen_bui
     res = []
     for noflag in ("0", "1"):
         monkeypatch.setenv("NMPC_BLOCK_NOFLAG", noflag)
+        monkeypatch.setenv("NMPC_QP_NOFLAG", noflag)          # k_team_tail / k_team_qp_list of the same solve: both builds too
         s = NmpcOcpSolver(_lib.default_config(N=N, max_batch=B))
         out = s.solve_batch(x0, yref, ye, want_traj=True)
         it, ps = s.counts()

@@ -546,13 +546,15 @@ def test_three_and_four_integrator_steps_per_stage_linearisation_with_trajectori
 
 @pytest.mark.parametrize("share", [1, 0])
 def test_flag_build_of_the_interior_point_kernel_is_bit_equal_to_the_default_codegen_build(share, monkeypatch):
-    """k_team_qp - the whole interior-point QP for the whole batch (qp_polish = 0, or an attempt schedule that starts with iterations) - is
-    built twice since round 4: nmpc_qpf.hip with -mllvm -amdgpu-mfma-vgpr-form (12 % fewer instructions: no accumulation-register moves),
+    """The kernels that iterate the interior point method - k_team_qp (whole QP, whole batch: qp_polish = 0, or an attempt schedule that
+    starts with iterations) and k_team_qp_list (the work list of the default path) - are built twice since round 4: nmpc_qpf.hip with -mllvm -amdgpu-mfma-vgpr-form (12 % fewer instructions: no accumulation-register moves),
     nmpc_qp.hip with the default code generation (NMPC_QP_NOFLAG=1).  Same arithmetic, different register placement: every output bit and
     every iteration count must agree - plain interior point and the single-kernel attempt schedule, cold and warm-started, trajectories."""
     yref, ye = hover(_lib.default_config())
     x0 = np.concatenate([sample_x0(200, 91, **NEAR_HOVER), sample_x0(200, 92, **AGGRESSIVE), sample_x0(111, 93, **WILD)])
-    for over in (dict(qp_polish=0), dict(qp_polish=1, qp_polish_mu=1e-2)):
+    # plain interior point | single-kernel attempt schedule (both k_team_qp) | default split path with tight attempts (k_team_qp_list drains
+    # a well-filled work list: the wild third of the sample)
+    for over in (dict(qp_polish=0), dict(qp_polish=1, qp_polish_mu=1e-2), dict(qp_polish=1, qp_polish_passes=3, qp_polish_budget=6)):
         res = []
         for noflag in ("0", "1"):
             monkeypatch.setenv("NMPC_QP_NOFLAG", noflag)

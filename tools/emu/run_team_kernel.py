@@ -48,7 +48,7 @@ def layout_and_consts(cfg_bytes: bytes, csrc: Path, inc: Path):
 
 
 def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, seed=8, dist="aggressive", csrc=None, inc=None, warm=False,
-            trace=False, max_steps=40_000_000, kind="qp", verbose=True):
+            trace=False, max_steps=40_000_000, kind="qp", verbose=True, lds_overlap=True):
     from rotors_mpc_controller_amd import _lib
     from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
     csrc = Path(csrc or ROOT / "rotors_mpc_controller_amd" / "csrc")
@@ -122,11 +122,12 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
     tpw = 4 if B >= 2048 else (2 if B >= 512 else 1)
     # LDS carve (nmpc_capi.hip: as_lds_base / qp_lds / launch_split)
     A_EV, AS_EV, AS_CH = 312, 56, 8
-    base = (A_EV + AS_EV + (AS_EV if steps > 2 else 0)) if shared else (A_EV + AS_CH * AS_EV)
+    carve = (A_EV + AS_EV + (AS_EV if steps > 2 else 0)) if shared else (A_EV + AS_CH * AS_EV)
+    base = carve if (shared or not lds_overlap) else A_EV          # as_cache_base: the per-stage cache starts at the (dead) evaluation points
     lm_rows = 88 if kind == "qp" else 80
     per_team = 40960 // 4 // 8
     lstg = max(0, min(N, (per_team - base - 31) // lm_rows))
-    stride = base + lstg * lm_rows
+    stride = max(carve, base + lstg * lm_rows)
     stride += (24 - stride % 32 + 32) % 32
     lds_bytes = 4 * stride * 8
     for i, v in enumerate((B, tpw, stride, lstg, base)):
