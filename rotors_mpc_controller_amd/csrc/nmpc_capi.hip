@@ -121,6 +121,7 @@ struct nmpc_solver {
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
     int block_noflag = 0;            // NMPC_BLOCK_NOFLAG=1: block kernels from nmpc_block.hip (default code generation) instead of nmpc_blockf.hip
+    int lds_pad = 24;                // NMPC_LDS_PAD=<0..31> (experiments): team stride mod 32 doubles
     int lds_overlap = 1;             // NMPC_LDS_OVERLAP=0: the per-stage variant's stage cache behind the evaluation-point buffer (round 3)
     int qp_noflag = 0;               // NMPC_QP_NOFLAG=1: k_team_qp from nmpc_qp.hip (default code generation) instead of nmpc_qpf.hip
     int as_v256 = 0;                 // NMPC_AS_BUILD=v256: the 256-register build with the LDS stage cache (nmpc_qp.hip, OCC = 3)
@@ -398,6 +399,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LDS_OVERLAP")) s->lds_overlap = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_LDS_PAD")) s->lds_pad = std::max(0, std::min(31, std::atoi(e)));
     if (const char *e = std::getenv("NMPC_BLOCK_NOFLAG")) s->block_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_BUILD")) {
         s->as_v256 = std::strcmp(e, "v256") == 0;
@@ -552,7 +554,7 @@ static int as_cache_base(const nmpc_solver *s, bool shared)
 static int as_lds_stride(const nmpc_solver *s, bool shared, int lstg, int rows)
 {
     int stride = std::max(as_lds_base(s, shared), as_cache_base(s, shared) + lstg * rows);
-    stride += (24 - stride % 32 + 32) % 32;
+    stride += (s->lds_pad - stride % 32 + 32) % 32;          // (NMPC_LDS_PAD: residue of the team stride mod 32 doubles; 24 = 192 B past a bank row)
     return stride;
 }
 

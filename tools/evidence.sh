@@ -2,7 +2,7 @@
 # The measured evidence of a round in one GPU call: rocprofv3 captures (kernel trace + PMC passes) of the default workload, of the
 # plain interior point and of config 5, the bench table of DESIGN.md section 5, the full bench.py line, the block-factorisation table.
 #   gpurun --timeout 1100 -- bash tools/evidence.sh r03          (outputs under gpurun_out/; copy what is to be judged into profiles/)
-TAG=${1:-r03}
+TAG=${1:-r04}
 mkdir -p gpurun_out
 set -e
 bash tools/rocprof_capture.sh $TAG > gpurun_out/${TAG}_capture.log 2>&1
