@@ -3,7 +3,7 @@
 # the host build of the kernel bodies with AddressSanitizer + UndefinedBehaviorSanitizer and runs the whole
 # `not gpu` suite on them.  Output -> profiles/<tag>_asan_ubsan_cpu_suite.txt
 #   usage: bash tools/run_sanitized_tests.sh [tag]
-TAG=${1:-r02}
+TAG=${1:-r04}
 cd "$(dirname "$0")/.."
 OUT=profiles/${TAG}_asan_ubsan_cpu_suite.txt
 ASAN_LIB=$(gcc -print-file-name=libasan.so)
