@@ -533,10 +533,6 @@ static int as_lds_base(const nmpc_solver *s, bool shared)
     return shared ? TEAM_AS_LDS_SHARED + (s->cfg.sim_num_steps > 2 ? AS_EV : 0) : TEAM_AS_LDS_STAGE;
 }
 
-// Where a team's stage cache starts.  The evaluation-point buffer of the linearisation (per-stage variant: 448 of a team's 1280 doubles)
-// is dead once the preparation has run, so the cache of the per-stage variant starts AT it (A_EV) instead of behind it: five more stages
-// of factors stay in LDS (11 instead of 6 in k_team_as).  The shared variant's single stage of evaluation points is small and stays.
-// NMPC_LDS_OVERLAP=0 restores the round-3 placement.
 // the kernels that iterate the interior point method: the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator
 // steps, as k_team_as - else (and with NMPC_QP_NOFLAG=1) the default code generation (nmpc_qp.hip)
 template <class TI>
@@ -546,6 +542,10 @@ static int launch_qp_kind(const nmpc_solver *s, const AsLaunch &a, const Inputs<
     return launch_team_qp(a, in, out);
 }
 
+// Where a team's stage cache starts.  The evaluation-point buffer of the linearisation (per-stage variant: 448 of a team's 1280 doubles)
+// is dead once the preparation has run, so the cache of the per-stage variant starts AT it (A_EV) instead of behind it: five more stages
+// of factors stay in LDS (11 instead of 6 in k_team_as).  The shared variant's single stage of evaluation points is small and stays.
+// NMPC_LDS_OVERLAP=0 restores the round-3 placement.
 static int as_cache_base(const nmpc_solver *s, bool shared)
 {
     return (shared || !s->lds_overlap) ? as_lds_base(s, shared) : A_EV;
