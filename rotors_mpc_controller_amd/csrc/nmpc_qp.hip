@@ -1,23 +1,20 @@
-// nmpc_qp.hip -- the kernels of nmpc_team_as.hpp that are built with the compiler's DEFAULT code generation: k_team_qp (the whole QP,
-// whole batch), k_team_qp_list (work-list continuation) and a second build of k_team_as.
+// nmpc_qp.hip -- the kernels of nmpc_team_as.hpp with the compiler's DEFAULT code generation: k_team_as (first launch), k_team_qp (the whole QP,
+// whole batch), k_team_qp_list (work-list continuation), k_team_tail (long-horizon tail).
 //
-// Why a translation unit of its own: nmpc_as.hip is compiled with -mllvm -amdgpu-mfma-vgpr-form (+7 % on the headline kernel), an INTERNAL
-// LLVM option that is validated for exactly one configuration - k_team_as at sim_num_steps <= 2: bit-equal on the GPU to this file's build
-// of the same kernel (NMPC_AS_NOFLAG=1 selects it), and executed instruction by instruction on the CPU by tools/emu with every address
-// checked (tests/test_isa_emulation.py).  Everything else is built here, with the default code generation.  (Round 3 wrote that the flag
-// "miscompiles" k_team_qp<per-stage, trajectories>, after a GPU memory fault on sim_num_steps = 4 inputs.  Round 4 emulated that launch on
-// the flag build - all 256 workgroups, 32 M instructions, no access outside a buffer, the oracle's answers - and withdrew the claim: the
-// fault came from an uncommitted working tree.  DESIGN.md section 4.2 has the examination.)
+// What runs by default is the -mllvm -amdgpu-mfma-vgpr-form build of the same sources (nmpc_as.hip: k_team_as; nmpc_qpf.hip, which includes
+// this file: the other three) - an INTERNAL LLVM option, so every flag build is held bit-equal to this file's build of the same kernel on
+// the GPU (NMPC_AS_NOFLAG / NMPC_QP_NOFLAG select this file; tests/test_gpu_parity.py) and is executed instruction by instruction on the CPU
+// by tools/emu with every address checked (tests/test_isa_emulation.py).  This file's builds are also what sim_num_steps > 2 runs.
+// (Round 3 wrote that the flag "miscompiles" k_team_qp<per-stage, trajectories>, after a GPU memory fault on sim_num_steps = 4 inputs.
+// Round 4 emulated that launch on the flag build - all 256 workgroups, 32 M instructions, no access outside a buffer, the oracle's
+// answers - and withdrew the claim: the fault came from an uncommitted working tree.  DESIGN.md section 4.2 has the examination.)
 #include <hip/hip_runtime.h>
 
 #include "nmpc_as_launch.hpp"
 
 using namespace nmpc;
 
-// nmpc_qpf.hip includes this file with NMPC_QP_WHOLE_BATCH_ONLY to build the kernels that iterate the interior point method - k_team_qp
-// (whole QP, whole batch), k_team_qp_list (work list), k_team_tail (long-horizon tail) - a second time with -amdgpu-mfma-vgpr-form
-// (round 4: validated like k_team_as - bit-equal to this file's builds on the GPU, k_team_qp executed instruction by instruction by
-// tools/emu); the exported launcher then has another name
+// nmpc_qpf.hip includes this file with NMPC_QP_WHOLE_BATCH_ONLY (everything but k_team_as); the exported launcher then has another name
 #ifndef NMPC_QP_EXPORT
 #define NMPC_QP_EXPORT launch_team_qp
 #endif

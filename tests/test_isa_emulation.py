@@ -1,11 +1,13 @@
-"""The shipped code-generation of the default path's first launch, executed on the CPU.
+"""The shipped code generation of the default path, executed on the CPU.
 
-k_team_as (csrc/nmpc_as.hip) is the one kernel built with the internal LLVM option -amdgpu-mfma-vgpr-form.  tools/emu/gfx950_emu.py is a
-functional emulator of a gfx950 wave that reads the compiler's own assembly of that translation unit (make build/nmpc_as.s: same flags as
-the shipped object): these tests run workgroups of the headline configuration and of the warm-started per-stage configuration through it,
-registers and LDS poisoned, every global access checked against buffers of nmpc_create's sizes and every LDS access against the launch's
-allocation, and compare the commands with the oracle.  No GPU involved: what is under test is the INSTRUCTION STREAM of the flag build
-(DESIGN.md section 4.2 has why; the GPU-side guard is test_flag_build_of_the_active_set_kernel_is_bit_equal_to_the_default_codegen_build).
+The solver kernels that run by default (csrc/nmpc_as.hip: k_team_as; csrc/nmpc_qpf.hip: k_team_qp, k_team_qp_list, k_team_tail) are built with
+the internal LLVM option -amdgpu-mfma-vgpr-form.  tools/emu/gfx950_emu.py is a functional emulator of a gfx950 wave that reads the compiler's
+own assembly of those translation units (make build/nmpc_as.s, build/nmpc_qpf.s: same flags as the shipped objects): these tests run
+workgroups of the headline configuration, of the warm-started per-stage configuration, of the plain interior-point kernel and of the two
+launches of the default path in sequence through it, registers, LDS and scratch poisoned, every global access checked against buffers of
+nmpc_create's sizes, every LDS access against the launch's allocation, every scratch access against the kernel's private segment, and
+compare the results with the oracle.  No GPU involved: what is under test is the INSTRUCTION STREAM of the flag builds (DESIGN.md section
+4.2 has why; the GPU-side guards are the test_flag_build_of_..._is_bit_equal_to_the_default_codegen_build tests).
 """
 import os
 import shutil
@@ -66,6 +68,48 @@ def test_shipped_flag_build_of_the_interior_point_kernel():
     workgroups of four instances through ~80 k instructions each."""
     s = _asm("nmpc_qpf.s")
     _check(s, "k_team_qpILb1ELb0EdEE", range(0, 2), steps=2, polish=0, share=1, B=2048, dist="near_hover", seed=0, kind="qp")
+
+
+def _check_hand_over(as_kernel, list_kernel, wgs, warm):
+    """First launch, then the work-list launch on the memory it left (pass budget of ONE pass per attempt, so that every instance that pins an
+    input is handed over): addresses of both instruction streams, scratch reloads against their spills, statuses / iteration counts /
+    commands / trajectories of every instance of the workgroup against the oracle."""
+    import run_team_kernel as R
+    from oracle import oracle as O
+    over = dict(qp_polish_passes=1, qp_polish_budget=2)
+    handed = 0
+    for wg in wgs:
+        r = R.emulate(_asm("nmpc_as.s"), as_kernel, wg=wg, verbose=False, steps=2, polish=1, share=1, B=2048, dist="aggressive", seed=1, kind="as",
+                      warm=warm, cfg_over=over, then=(_asm("nmpc_qpf.s"), list_kernel))
+        s2 = r["second"]
+        assert r["error"] is None and s2["error"] is None, (r["error"], s2["error"])
+        for v in (r["violations"], s2["violations"]):
+            assert not v, [(x.kind, x.line, x.text, x.lane, hex(x.addr), x.note) for x in v[:4]]
+        handed += len(r["listed"])
+        c = O.default_config(N=20, qp_gamma=0.0, qp_polish=1, sim_num_steps=2, **over)
+        sl = slice(r["inst"], r["inst"] + r["tpw"])
+        ref = O.solve_batch(c, r["x0"][sl], r["yref"], r["ye"], x_init=None if not warm else r["x_init"][sl],
+                            u_init=None if not warm else r["u_init"][sl], want_traj=True)
+        B = len(r["x0"])
+        m = r["mem"]
+        assert (m.view("status", np.int32)[sl] == ref["status"]).all() and (m.view("d_iters", np.int32)[sl] == ref["iters"]).all()
+        assert np.abs(m.view("u0", np.float64).reshape(B, 4)[sl] - ref["u0"]).max() < 1e-9
+        if warm:
+            assert np.abs(m.view("x_out", np.float64).reshape(B, 21, 13)[sl] - ref["x"]).max() < 1e-9
+            assert np.abs(m.view("u_out", np.float64).reshape(B, 20, 4)[sl] - ref["u"]).max() < 1e-9
+    assert handed >= 2, handed          # (the point of the case: the second launch had work)
+
+
+def test_shipped_flag_builds_of_both_launches_with_instances_handed_over():
+    """k_team_as<shared> -> k_team_qp_list<shared> (nmpc_qpf.hip): interior-point iterations and a second attempt for what the first launch's
+    single pass left over."""
+    _check_hand_over("k_team_asILb1ELb0ELi1EdEE", "k_team_qp_listILb1ELb0EdEE", range(0, 2), warm=False)
+
+
+def test_shipped_flag_builds_of_both_launches_per_stage_with_trajectories():
+    """... and the warm-started per-stage variants with trajectories, whose work-list kernel is the one shipped kernel with spills (44 B of
+    scratch per lane): the emulator keeps the private segment per lane and flags a reload of a byte no spill wrote."""
+    _check_hand_over("k_team_asILb0ELb1ELi1EdEE", "k_team_qp_listILb0ELb1EdEE", range(0, 2), warm=True)
 
 
 @pytest.mark.skipif(os.environ.get("NMPC_EMU_FULL") != "1", reason="NMPC_EMU_FULL=1: compiles nmpc_qp.hip with the flag (minutes); profiles/r04_emulation_*.txt holds the full runs")

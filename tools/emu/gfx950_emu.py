@@ -267,6 +267,9 @@ class Wave:
         self.steps = 0
         self.max_steps = max_steps
         self.stop_on_violation = stop_on_violation
+        self.scratch_bytes = 0                             # the kernel's private_segment_fixed_size (set by the harness when the kernel spills)
+        self.scratch = np.full((64, 4096), 0xFD, dtype=np.uint8)
+        self.scratch_set = np.zeros((64, 4096), dtype=bool)
         self.trace_mem = None                              # optional list of (line, kind, lane, addr, nbytes) for address-stream comparison
         if poison:
             # registers and LDS start with garbage on the hardware: a poison pattern (a NaN as a double, a wild pointer as an address)
@@ -998,6 +1001,51 @@ def _global_store(w, ins):
     w.gstore(addrs, buf[:, :n], n, lanes)
 
 
+def _scratch_addr(w, ins, vaddr, saddr):
+    a = np.full(64, ins.mods.get("offset", 0), dtype=np.int64)
+    if vaddr.kind != "off":
+        a = a + w.rv32(vaddr).astype(np.int64)
+    if saddr.kind != "off":
+        a = a + np.int64(w.rs(saddr, 32))
+    return a
+
+
+def _scratch_load(w, ins):
+    # private (per-lane) memory of the wave: spills.  Bounds = the kernel's private_segment_fixed_size (Wave.scratch_bytes); a read of a byte
+    # no store has written is a violation too (a reload without its spill)
+    n = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}[ins.op[len("scratch_load_"):]]
+    d, vaddr, saddr = ins.ops[0], ins.ops[1], ins.ops[2] if len(ins.ops) > 2 else Op("off")
+    a = _scratch_addr(w, ins, vaddr, saddr)
+    out = np.zeros((64, n), dtype=np.uint8)
+    for l in np.nonzero(w.mask())[0]:
+        o = int(a[l])
+        if o < 0 or o + n > w.scratch_bytes:
+            w._viol("scratch-read", l, o, n, f"private segment {w.scratch_bytes}")
+            continue
+        if not w.scratch_set[l, o:o + n].all():
+            w._viol("scratch-read", l, o, n, "never written")
+        out[l] = w.scratch[l, o:o + n]
+    words = out.view(np.uint32).reshape(64, n // 4)
+    for i in range(n // 4):
+        w.wv32(Op(d.kind, d.n + i), words[:, i])
+
+
+def _scratch_store(w, ins):
+    n = {"dword": 4, "dwordx2": 8, "dwordx3": 12, "dwordx4": 16}[ins.op[len("scratch_store_"):]]
+    vaddr, data, saddr = ins.ops[0], ins.ops[1], ins.ops[2] if len(ins.ops) > 2 else Op("off")
+    a = _scratch_addr(w, ins, vaddr, saddr)
+    buf = np.zeros((64, n), dtype=np.uint8)
+    for i in range(n // 4):
+        buf[:, 4 * i:4 * i + 4] = w.rv32(Op(data.kind, data.n + i)).view(np.uint8).reshape(64, 4)
+    for l in np.nonzero(w.mask())[0]:
+        o = int(a[l])
+        if o < 0 or o + n > w.scratch_bytes:
+            w._viol("scratch-write", l, o, n, f"private segment {w.scratch_bytes}")
+            continue
+        w.scratch[l, o:o + n] = buf[l]
+        w.scratch_set[l, o:o + n] = True
+
+
 def _ds_read(w, ins):
     op = ins.op
     lanes = np.nonzero(w.mask())[0]
@@ -1207,6 +1255,8 @@ _PATTERNS = [
     (r"v_mfma_f64_4x4x4_4b_f64", _v_mfma_f64_4x4x4),
     (r"global_load_(dword|dwordx2|dwordx3|dwordx4|ushort|sshort|sbyte|ubyte)", _global_load),
     (r"global_store_(dword|dwordx2|dwordx3|dwordx4|short|byte)", _global_store),
+    (r"scratch_load_(dword|dwordx2|dwordx3|dwordx4)", _scratch_load),
+    (r"scratch_store_(dword|dwordx2|dwordx3|dwordx4)", _scratch_store),
     (r"ds_read2?_b(32|64|128)", _ds_read),
     (r"ds_write2?_b(32|64|128)", _ds_write),
     (r"ds_bpermute_b32", _ds_bpermute),

@@ -47,14 +47,44 @@ def layout_and_consts(cfg_bytes: bytes, csrc: Path, inc: Path):
     return json.loads(out.stdout), (tmp / "consts.bin").read_bytes()
 
 
+def hidden_offsets(sfile: str, kernel: str) -> dict:
+    """kernarg offsets of the hidden arguments of a kernel, from the metadata the compiler wrote into the assembly."""
+    lines = open(sfile).read().split("\n")
+    for i, l in enumerate(lines):
+        if ".name:" in l and kernel in l:
+            j = i
+            while not lines[j].startswith("  - .agpr_count"):
+                j -= 1
+            out = {}
+            for k in range(j, i):
+                if "value_kind" in lines[k] and "hidden_" in lines[k]:
+                    out[lines[k].split()[-1]] = int(lines[k - 2].split()[-1])
+            return out
+    raise KeyError(kernel)
+
+
+def private_segment_size(sfile: str, kernel: str) -> int:
+    lines = open(sfile).read().split("\n")
+    for i, l in enumerate(lines):
+        if ".name:" in l and kernel in l:
+            for k in range(i, min(i + 12, len(lines))):
+                if ".private_segment_fixed_size:" in lines[k]:
+                    return int(lines[k].split()[-1])
+    raise KeyError(kernel)
+
+
 def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, seed=8, dist="aggressive", csrc=None, inc=None, warm=False,
-            trace=False, max_steps=40_000_000, kind="qp", verbose=True, lds_overlap=True):
+            trace=False, max_steps=40_000_000, kind="qp", verbose=True, lds_overlap=True, cfg_over=None, then=None):
+    """cfg_over: nmpc_config fields to override (e.g. qp_polish_passes); then = (file.s, kernel): after a k_team_as workgroup, run workgroup 0 of
+    that k_team_qp_list build on the SAME memory - the second launch of the default path, on the work list the first workgroup left."""
     from rotors_mpc_controller_amd import _lib
     from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
     csrc = Path(csrc or ROOT / "rotors_mpc_controller_amd" / "csrc")
     inc = Path(inc or ROOT / "include")
     N = 20
     cfg = _lib.default_config(N=N, max_batch=B, sim_num_steps=steps, qp_polish=polish, flags=_lib.FLAG_TEAM_MAPPING | (1 if share else 0))
+    if cfg_over:
+        cfg.update(**cfg_over)
     lay, consts = layout_and_consts(bytes(cfg)[:10 ** 6], csrc, inc)
     cfg_bytes = bytes(cfg)[:lay["sizeof.config"]]                  # (an older tree's nmpc_config is a prefix of the current one)
     lay, consts = layout_and_consts(cfg_bytes, csrc, inc)
@@ -137,6 +167,7 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
     kaddr = mem.add("kernarg", np.frombuffer(bytes(ka), dtype=np.uint8), writable=False)
     insts, labels = E.parse_kernel(sfile, kernel)
     w = E.Wave(insts, labels, mem, lds_bytes, kaddr, wg, symbols, max_steps=max_steps)
+    w.scratch_bytes = private_segment_size(sfile, kernel)
     if trace:
         w.trace_mem = []
     t = time.time()
@@ -147,13 +178,45 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
         err = str(e)
     dt = time.time() - t
     inst = wg * tpw
+    second = None
+    if then is not None and err is None:
+        # the work-list launch (launch_split: grid min((B + 3) / 4, 64), LDS carve of qp_lds with IP_LM_ROWS rows per cached stage)
+        sfile2, kernel2 = then
+        lstg2 = max(0, min(N, (per_team - base - 31) // 88))
+        stride2 = max(carve, base + lstg2 * 88)
+        stride2 += (24 - stride2 % 32 + 32) % 32
+        ka2 = bytearray(512)
+        ka2[:248] = ka[:248]
+        for i, v in enumerate((B, stride2, lstg2, base)):
+            struct.pack_into("<i", ka2, 248 + 4 * i, v)
+        hid = hidden_offsets(sfile2, kernel2)
+        struct.pack_into("<III", ka2, hid["hidden_block_count_x"], min((B + 3) // 4, 64), 1, 1)
+        struct.pack_into("<HHH", ka2, hid["hidden_group_size_x"], 64, 1, 1)
+        if "hidden_dynamic_lds_size" in hid:
+            struct.pack_into("<I", ka2, hid["hidden_dynamic_lds_size"], 4 * stride2 * 8)
+        kaddr2 = mem.add("kernarg2", np.frombuffer(bytes(ka2), dtype=np.uint8), writable=False)
+        sym2 = {}
+        for name, data in E.parse_rodata(sfile2, SYMS).items():
+            sym2[name] = mem.add("second:" + name, np.frombuffer(data, dtype=np.uint8), writable=False)
+        insts2, labels2 = E.parse_kernel(sfile2, kernel2)
+        w2 = E.Wave(insts2, labels2, mem, 4 * stride2 * 8, kaddr2, 0, sym2, max_steps=max_steps)
+        w2.scratch_bytes = private_segment_size(sfile2, kernel2)
+        err2 = None
+        n_listed = int(mem.view("d_wl", np.int32)[0])
+        try:
+            w2.run()
+        except E.EmuError as e:
+            err2 = str(e)
+        second = dict(instructions=w2.steps, error=err2, violations=w2.viol, listed=n_listed, lds_bytes=4 * stride2 * 8, lstg=lstg2)
     u0 = mem.view("u0", f8).reshape(B, NU)[inst:inst + tpw].copy()
     st = mem.view("status", np.int32)[inst:inst + tpw].copy()
     its = mem.view("d_iters", np.int32)[inst:inst + tpw].copy()
     wlv = mem.view("d_wl", np.int32)
     listed = sorted(int(x) for x in wlv[2:2 + int(wlv[0])])
+    if second is not None:
+        listed = sorted(int(x) for x in wlv[2:2 + second["listed"]])
     res = dict(listed=listed, file=sfile, kernel=kernel, instructions=w.steps, seconds=dt, error=err, u0=u0, status=st, iters=its, violations=w.viol,
-               lds_bytes=lds_bytes, lstg=lstg, trace=w.trace_mem, addr=addr, mem=mem, x0=x0, yref=yref, ye=ye, x_init=xi, u_init=ui, inst=inst, tpw=tpw)
+               lds_bytes=lds_bytes, lstg=lstg, trace=w.trace_mem, second=second, addr=addr, mem=mem, x0=x0, yref=yref, ye=ye, x_init=xi, u_init=ui, inst=inst, tpw=tpw)
     if verbose:
         print(f"{Path(sfile).name} [{kernel}] wg {wg}: {w.steps} instructions in {dt:.1f} s, error {err}, violations {len(w.viol)}; status {st} iters {its}")
         for v in w.viol[:12]:
