@@ -346,6 +346,8 @@ class Wave:
             self.set_s64(106, v)
         elif k == "vcc_lo":
             self.set_s32(106, v)
+        elif k == "vcc_hi":
+            self.set_s32(107, v)
         elif k == "exec":
             self.exec_ = v & M64
         else:
@@ -684,8 +686,12 @@ def _s_load(w, ins):
     off = ins.ops[2].val if ins.ops[2].kind == "lit" else w.rs(ins.ops[2])
     raw = w.sload(base + off, 4 * n)
     vals = struct.unpack(f"<{n}I", raw)
+    d = ins.ops[0]
+    if d.kind not in ("s", "vcc"):
+        raise EmuError(f"s_load destination {d}")
+    first = 106 if d.kind == "vcc" else d.n          # (the compiler uses vcc as an ordinary register pair where no compare needs it)
     for i, v in enumerate(vals):
-        w.set_s32(ins.ops[0].n + i, v)
+        w.set_s32(first + i, v)
 
 
 def _s_getpc(w, ins):
