@@ -119,3 +119,51 @@ def test_the_configuration_that_faulted_in_round_3_on_the_flag_build_of_k_team_q
     s = _asm("nmpc_qp_flag.s")
     _check(s, "k_team_qpILb0ELb1EdEE", range(0, 8), steps=4, polish=0, share=0, B=256, dist="aggressive", seed=8, kind="qp")
     _check(s, "k_team_qpILb0ELb1EdEE", range(0, 4), steps=4, polish=0, share=0, B=256, dist="aggressive", seed=8, kind="qp", warm=True)
+
+
+def _run_snippet(tmp_path, body, scratch_bytes=0):
+    """Emulate a hand-written instruction sequence: s[0:1] = address of a 64-byte read-only block holding the double 2.5 at offset 8,
+    s[2:3] = address of a 512-byte output buffer."""
+    import gfx950_emu as E
+    f = tmp_path / "snippet.s"
+    f.write_text("_Zsnippet:\n" + body + "\n\ts_endpgm\n.Lfunc_end0:\n")
+    mem = E.Memory()
+    src = np.zeros(8, dtype=np.float64); src[1] = 2.5
+    a_in = mem.add("in", np.frombuffer(src.tobytes(), dtype=np.uint8).copy(), False)
+    a_out = mem.add("out", np.zeros(512, dtype=np.uint8), True)
+    insts, labels = E.parse_kernel(str(f), "snippet")
+    w = E.Wave(insts, labels, mem, 0, a_in, 0, {})
+    w.S[2], w.S[3] = a_out & 0xFFFFFFFF, a_out >> 32
+    w.scratch_bytes = scratch_bytes
+    w.run()
+    return w, mem.view("out", np.float64)
+
+
+def test_emulator_treats_vcc_as_an_ordinary_register_pair(tmp_path):
+    """The iterative-ilp builds load constants into vcc (s_load_dwordx2 vcc, ...) and write vcc_hi on its own; the emulator once put such a load
+    into s[0:1] - found because the emulated work-list kernel then disagreed with the oracle."""
+    w, out = _run_snippet(tmp_path, """
+\ts_load_dwordx2 vcc, s[0:1], 0x8
+\ts_waitcnt lgkmcnt(0)
+\tv_mul_f64 v[2:3], vcc, 2.0
+\tv_lshlrev_b32_e32 v4, 3, v0
+\tglobal_store_dwordx2 v4, v[2:3], s[2:3]
+\ts_mov_b32 vcc_hi, 0
+\ts_mov_b32 vcc_lo, 5
+\tv_mov_b32_e32 v5, vcc_lo""")
+    assert not w.viol and (out == 5.0).all()
+    assert int(w.S[0]) | (int(w.S[1]) << 32) == w.mem.find(int(w.S[0]) | (int(w.S[1]) << 32), 8).base     # the kernarg pointer is untouched
+    assert (w.R[5] == 5).all() and int(w.S[107]) == 0
+
+
+def test_emulator_checks_scratch_against_the_private_segment_and_its_spills(tmp_path):
+    body = """
+\tv_mov_b32_e32 v1, 7
+\tscratch_store_dword off, v1, off offset:4
+\tscratch_load_dword v2, off, off offset:4
+\tscratch_load_dword v3, off, off offset:8
+\tscratch_store_dword off, v1, off offset:16"""
+    w, _ = _run_snippet(tmp_path, body, scratch_bytes=16)
+    assert (w.R[2] == 7).all()
+    kinds = sorted({(v.kind, v.note.split()[0]) for v in w.viol})
+    assert kinds == [("scratch-read", "never"), ("scratch-write", "private")], kinds
