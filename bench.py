@@ -336,6 +336,7 @@ def main() -> None:
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # multi-process GPU work on this pool needs dmabuf IPC (already exported on the boxes)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world_env:
         if world_env == 1 and args.gpus > 1:
