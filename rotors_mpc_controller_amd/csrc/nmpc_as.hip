@@ -15,22 +15,20 @@ namespace {
 template <bool SHARED, bool TRAJ, int OCC, class TI>
 __global__ __launch_bounds__(64, OCC) void k_team_as(const Consts<double> *__restrict__ cp, Work<double> w, Inputs<TI> in, Outputs<TI> out,
                                                      TeamWork<double> tw, WorkList wl, int B, int tpw, int lds_stride, int lstg, int lm_off,
-                                                     int pass_cap, double *tail_ts)
+                                                     int pass_cap, double *tail_ts, int cont_stride, int cont_lstg)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     // the constant block is read from device memory (uploaded at create): scalar loads on demand for uniform entries,
     // one vector load for a per-lane entry
-    // (pass_cap > 0: long horizons - the attempt is handed to the block-parallel tail after that many passes, tail_ts its state rows)
-    TailCtx tcx;
-    tcx.cap = pass_cap; tcx.ts = tail_ts;
-    team_as<SHARED, TRAJ, OCC == 1, TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg, lm_off, -2, tcx);
+    team_as_kernel<SHARED, TRAJ, OCC == 1, OCC == 1 && as_cont_built(SHARED, TRAJ), TI>(*cp, w, in, out, tw, wl, B, tpw, reinterpret_cast<double *>(smem_raw), lds_stride, lstg,
+                                                          lm_off, pass_cap, tail_ts, cont_stride, cont_lstg);
 }
 
 template <class TI>
 int launch_impl(const AsLaunch &a, const Inputs<TI> &in, const Outputs<TI> &out)
 {
     const dim3 grid((a.B + a.tpw - 1) / a.tpw), block(64);
-#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off, a.tail.cap, a.tail.ts)
+#define NMPC_LAUNCH_AS(SH_, TR_, OC_) hipLaunchKernelGGL((k_team_as<SH_, TR_, OC_, TI>), grid, block, a.lds_bytes, a.stream, a.cp, a.w, in, out, a.tw, a.wl, a.B, a.tpw, a.lds_stride, a.lstg, a.lm_off, a.tail.cap, a.tail.ts, a.cont_stride, a.cont_lstg)
     if (a.shared) {
         if (a.occ == 2) { if (a.traj) NMPC_LAUNCH_AS(true, true, 2); else NMPC_LAUNCH_AS(true, false, 2); }
         else { if (a.traj) NMPC_LAUNCH_AS(true, true, 1); else NMPC_LAUNCH_AS(true, false, 1); }

@@ -21,6 +21,8 @@ struct AsLaunch {
                                 // 3: k_team_tail (one step of the block-parallel tail), 4: reset of a work list
     TailCtx tail;               // kind 3
     int nlist = 0;              // workgroups of the work-list launch
+    int cont_stride = 0, cont_lstg = 0;   // kind 0, one-wave builds: > 0 = failed first attempts continue on their own wave (team stride and cached
+                                // stages of the MODE 2 carve: IP_LM_ROWS per stage); 0 = they go to the work list
     bool shared, traj;
     size_t lds_bytes;
     hipStream_t stream;

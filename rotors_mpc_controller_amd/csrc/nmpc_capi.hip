@@ -119,6 +119,8 @@ struct nmpc_solver {
     double *d_gbase = nullptr;       // growth certificate: first-factorisation value per instance (active-set kernel -> work-list launch)
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
+    int team_inplace = 1;            // a failed first attempt continues on its own wave inside k_team_as (no work-list launch); NMPC_TEAM_INPLACE=0:
+                                     // work list + k_team_qp_list (always so for long horizons - the block-parallel tail - and the 256-register builds)
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
     int block_noflag = 0;            // NMPC_BLOCK_NOFLAG=1: block kernels from nmpc_block.hip (default code generation) instead of nmpc_blockf.hip
     int lds_pad = 24;                // NMPC_LDS_PAD=<0..31> (experiments): team stride mod 32 doubles
@@ -396,6 +398,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TEAM_INPLACE")) s->team_inplace = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LDS_OVERLAP")) s->lds_overlap = std::atoi(e) != 0;
@@ -605,6 +608,14 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     al.lds_stride = lds_stride; al.lstg = lstg; al.lm_off = base_as; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
     al.lds_bytes = lds_as; al.stream = st;
     const bool tail = s->team_qp && s->tail_J > 0;
+    // failed first attempts continue inside k_team_as (team_as_kernel): the one-wave builds, the team_as kernels, short horizons
+    const bool inplace = s->team_inplace && s->team_qp && !tail && occ_as == 1 && !s->as_v256 && as_cont_built(c.shared != 0, traj);
+    if (inplace) {
+        AsLaunch ql = al;
+        qp_lds(s, c.shared != 0, ql);               // the MODE 2 carve: IP_LM_ROWS per cached stage, same base
+        al.cont_stride = ql.lds_stride; al.cont_lstg = ql.lstg;
+        al.lds_bytes = std::max(al.lds_bytes, ql.lds_bytes);
+    }
     const int cap = tail ? std::max(1, std::min(s->tail_cap > 0 ? s->tail_cap : s->cfg.qp_polish_passes, s->cfg.qp_polish_passes)) : 0;
     if (tail) {
         // the tail's lists are reset by its last launches; a solve that returned early with an error leaves counts behind, and the next
@@ -682,6 +693,8 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         AsLaunch rl = al;
         rl.kind = 4; rl.tail.nx_count = lists[1].count;
         HIP_TRY(s, (hipError_t)launch_team_qp(rl, in, out));
+    } else if (inplace) {
+        // nothing was handed over: every instance finished inside k_team_as
     } else if (s->team_qp) {
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);

@@ -63,6 +63,13 @@ constexpr int A_EV = A_RED + 40;     // evaluation points of the linearisation
 constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 368
 constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 760
 
+// Which builds of k_team_as carry the continuation of failed first attempts (team_as_kernel below; host and device agree through this one
+// function).  Not the per-stage build without trajectories: with the continuation inlined, the iterative-ilp build of THAT kernel parks a
+// live value in an accumulation register in front of the EXEC restore of a join block (tools/emu/exec_join_check.py finds the pattern,
+// tests/test_isa_emulation.py runs it on every flag build) - a code-generation fault of the scheduler strategy, so that kernel keeps the
+// work-list launch, which compiles clean.
+constexpr bool as_cont_built(bool shared, bool traj) { return shared || traj; }
+
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 
 // transposed Jacobian tiles at an evaluation point given as (q, omega, t2 = 2 (sum u) / m); re3 = (R e3 / m, 0): the thrust
@@ -103,6 +110,8 @@ struct TailCtx {
     int *fb_count = nullptr;         // fallback list: what the tail does not finish (solved by k_team_qp_list from the hand-over)
     int *fb_list = nullptr;
     int cap = 0;                     // MODE 0: passes the first launch performs before it hands a running attempt to the tail (0: all)
+    int inplace = 0;                 // MODE 0: a team whose first attempt fails is NOT appended to the work list - team_as returns true for its
+                                     // lanes and the kernel continues it at once (MODE 2 on the same wave: no second launch)
     double *frec = nullptr;          // [Bp + 1][J][FR_ROWS] records of the block-parallel forward sweep (phase 3 writes, phase 2 reads), or null
     const double *xb = nullptr;      // [Bp + 1][J][16] state at the start of every block (left by the boundary scan)
     int blk = 0, M = 0;              // phase 3: this team's block, stages per block
@@ -117,7 +126,7 @@ struct TailCtx {
 // MODE 3: ONE step of a work-list instance whose factorisation came from the block-parallel launches of nmpc_block.hpp (k_team_tail:
 //         long horizons) - no factor sweep in here
 template <bool SHARED, bool TRAJ, bool LDSC, class TI, int MODE = 0>
-__device__ __forceinline__ void team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
+__device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in,
                                         const Outputs<TI> &out, const TeamWork<double> &tw, const WorkList &wl,
                                         int B, int tpw, double *smem, int lds_stride, int lstg, int lm_off, int inst_ov = -2,
                                         const TailCtx tcx = TailCtx())
@@ -163,6 +172,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     // accepted results: from then on it works in the spare row too (pointers switched once per pass)
     T *const tLM_spare = tw.tLM + (size_t)w.Bp * N * TLM_ROWS, *const tIV_spare = tw.tIV + (size_t)w.Bp * N * IV_ROWS;
     T *const tP_spare = tw.tP ? tw.tP + (size_t)w.Bp * (ckpt + 1) * TP_ROWS : nullptr;
+    const bool have_tP = tw.tP != nullptr;      // (a kernel argument: branches on it are scalar; on the per-lane pointer tP they were divergent)
     T *tLM = tLM_own, *tIV = tIV_own, *tP = tP_own;
 
     int natR[4], natC[4];
@@ -478,7 +488,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                 });
             riccati_factor_stage<PINS, IPMV, LAST, true>(SL, sh, sHg, r, Aq0, Aq1b, Bt, sin, pol, true, Pt, gm, ok, nanp, so, sink);
             if (!LAST) {
-                if (!IPMV && tP && k <= wnd) {
+                if (!IPMV && have_tP && k <= wnd) {
                     T *cp = tP + (size_t)k * TP_ROWS + r;
                     NMPC_UNROLL for (int it = 0; it < 4; it++) {
                         NMPC_UNROLL for (int jt = 0; jt < 4; jt++) cp[(it * 4 + jt) * 16] = Pt[it][jt];
@@ -1072,7 +1082,7 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
         tLM = pol ? tLM_own : tLM_spare; tIV = pol ? tIV_own : tIV_spare; tP = pol ? tP_own : tP_spare;
         // the wave sweeps from the highest stage any of its live teams needs (wave-uniform trip count)
         ks = N - 1;
-        if (tP && pass > 0) {
+        if (have_tP && pass > 0) {
             if (r == 0) { sRed[28] = (T)(pol ? k_top : -1); sRed[29] = (T)(pol ? ck_valid : N); }
             __syncthreads();
             ks = 0;
@@ -1494,8 +1504,8 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
     }
     NMPC_PROF_END(w)
     tLM = tLM_own; tIV = tIV_own;
-    if (!valid) return;
-    if (MODE == 3 && !tail_fin) return;          // the instance is still in the tail, or went to the fallback list
+    if (!valid) return false;
+    if (MODE == 3 && !tail_fin) return false;    // the instance is still in the tail, or went to the fallback list
     if (MODE == 0 && mode == M_POL) {
         // the attempt is still running (pass cap of a long-horizon solve): its state goes to the tail's row - the pins of the next
         // pass are in the workspace already
@@ -1505,18 +1515,20 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
             const int slot = atomicAdd(wl.count, 1);
             wl.list[slot] = inst;
         }
-        return;
+        return false;
     }
     if (MODE == 0 && mode == M_GIVEUP) {
         if (r == 0) {
-            // the work-list launch resumes the pass budget from here (all of it spent when the growth certificate ended the
-            // attempt: the same pins would fail the same way) and compares against the same first factorisation
+            // the continuation (work-list launch, or MODE 2 on this wave) resumes the pass budget from here (all of it spent when the
+            // growth certificate ended the attempt: the same pins would fail the same way) and compares against the same first factorisation
             w.npol[inst] = -(tripped ? c.polish_budget : npol);
             w.gbase[inst] = warm_avail ? -gbase : gbase;     // < 0: the attempt ran out of passes, its last pass seeds the interior point
-            const int slot = atomicAdd(wl.count, 1);
-            wl.list[slot] = inst;
+            if (!tcx.inplace) {
+                const int slot = atomicAdd(wl.count, 1);
+                wl.list[slot] = inst;
+            }
         }
-        return;
+        return tcx.inplace != 0;
     }
     const bool accepted = nlp_status == 0;
     const int uoff = from_ua ? 12 : 0;                 // candidate inputs of the accepted pass | inputs of the iterate
@@ -1547,6 +1559,36 @@ __device__ __forceinline__ void team_as(const Consts<double> &c, const Work<doub
                     if (out.u_out && cmpl && k < N) out.u_out[((size_t)inst * N + k) * NU + j] = (TI)(accepted ? ulv[i] + uv[i] : T(0));
                 }
             }
+        }
+    }
+    return false;
+}
+
+// Body of k_team_as (built by two translation units: nmpc_as.hip and its default-codegen twin in nmpc_qp.hip).
+// CONT builds (one wave per SIMD) continue a team whose first attempt failed AT ONCE, on the same wave: team_as MODE 2 - what
+// k_team_qp_list runs for a work-list entry - from the hand-over record the attempt has just written.  No second launch then: on the
+// headline workload that launch found an empty list and cost 4.8 us of a 62 us step.  cont_stride = 0 keeps the work list (long horizons:
+// the block-parallel tail consumes it; NMPC_TEAM_INPLACE=0; the builds without CONT).  A team's results do not depend on which wave
+// continues it (the permutation tests), so the two schedules give the same bits.
+template <bool SHARED, bool TRAJ, bool LDSC, bool CONT, class TI>
+__device__ __forceinline__ void team_as_kernel(const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in, const Outputs<TI> &out,
+                                               const TeamWork<double> &tw, const WorkList &wl, int B, int tpw, double *smem, int lds_stride,
+                                               int lstg, int lm_off, int pass_cap, double *tail_ts, int cont_stride, int cont_lstg)
+{
+    // (pass_cap > 0: long horizons - the attempt is handed to the block-parallel tail after that many passes, tail_ts its state rows)
+    TailCtx tcx;
+    tcx.cap = pass_cap; tcx.ts = tail_ts;
+    tcx.inplace = (CONT && cont_stride > 0) ? 1 : 0;
+    const bool gave = team_as<SHARED, TRAJ, LDSC, TI>(c, w, in, out, tw, wl, B, tpw, smem, lds_stride, lstg, lm_off, -2, tcx);
+    if constexpr (CONT) {
+        if (cont_stride > 0 && __ballot(gave) != 0) {
+            __threadfence();                 // the hand-over (pass budget, certificate base, pin codes, warm start) is read back below
+            __syncthreads();
+            const int team = (threadIdx.x >> 2) & 3;
+            const int inst = gave ? (int)blockIdx.x * tpw + team : -1;
+            // (inlined on purpose: behind a call the arguments become generic pointers and the HOT path turns to flat loads and 244 B of
+            // scratch; inlined, the first attempt issues 3 % more instructions than without the continuation - register parking)
+            team_as<SHARED, TRAJ, true, TI, 2>(c, w, in, out, tw, wl, B, 4, smem, cont_stride, cont_lstg, lm_off, inst);
         }
     }
 }

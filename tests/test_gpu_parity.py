@@ -556,6 +556,8 @@ def test_flag_build_of_the_interior_point_kernel_is_bit_equal_to_the_default_cod
     # a well-filled work list: the wild third of the sample)
     for over in (dict(qp_polish=0), dict(qp_polish=1, qp_polish_mu=1e-2), dict(qp_polish=1, qp_polish_passes=3, qp_polish_budget=6)):
         res = []
+        # (failed first attempts are continued inside k_team_as by default: the work-list launch is what this case is about)
+        monkeypatch.setenv("NMPC_TEAM_INPLACE", "0" if "qp_polish_passes" in over else "1")
         for noflag in ("0", "1"):
             monkeypatch.setenv("NMPC_QP_NOFLAG", noflag)
             s = make_solver(flags=_lib.FLAG_TEAM_MAPPING | share, **over)
@@ -571,3 +573,36 @@ def test_flag_build_of_the_interior_point_kernel_is_bit_equal_to_the_default_cod
         np.testing.assert_array_equal(i0, i1)
         np.testing.assert_array_equal(j0, j1)
         assert i0.max() >= 3                      # (interior-point iterations really ran)
+
+
+@pytest.mark.parametrize("share,traj", [(1, False), (1, True), (0, True), (0, False)])
+def test_continuing_failed_attempts_inside_k_team_as_gives_the_bits_of_the_work_list_launch(share, traj, monkeypatch):
+    """Default since round 4: a team whose first active-set attempt fails is continued at once by the wave that made the attempt (team_as MODE 2
+    inside k_team_as) instead of being appended to a work list for a second launch (NMPC_TEAM_INPLACE=0; the per-stage build without
+    trajectories and long horizons keep the list).  Which wave continues an instance, and beside which wave-mates, must not show in a
+    single bit: outputs, trajectories, statuses, iteration and pass counts of the two schedules - tight pass budgets, so that the wild and
+    aggressive parts of the sample fail their first attempts by the hundred - cold and warm-started."""
+    yref, ye = hover(_lib.default_config())
+    x0 = np.concatenate([sample_x0(300, 71, **NEAR_HOVER), sample_x0(300, 72, **AGGRESSIVE), sample_x0(211, 73, **WILD)])
+    for over in (dict(qp_polish_passes=1, qp_polish_budget=2), dict(qp_polish_passes=3, qp_polish_budget=6), dict()):
+        res = []
+        for inplace in ("1", "0"):
+            monkeypatch.setenv("NMPC_TEAM_INPLACE", inplace)
+            s = make_solver(max_batch=len(x0), flags=_lib.FLAG_TEAM_MAPPING | share, **over)
+            a = s.solve_batch(x0, yref, ye, want_traj=traj)
+            ia, pa = s.iterations(), s.passes()
+            xi, ui = (a["x"], a["u"]) if traj else (None, None)
+            if xi is None:
+                t = s.solve_batch(x0, yref, ye, want_traj=True)
+                xi, ui = t["x"], t["u"]
+            b = s.solve_batch(x0, yref, ye, x_init=xi, u_init=ui, want_traj=traj)
+            res.append((a, ia, pa, b, s.iterations(), s.passes()))
+            s.close()
+        (a0, i0, p0, b0, j0, q0), (a1, i1, p1, b1, j1, q1) = res
+        for key in ("u0", "status") + (("x", "u") if traj else ()):
+            np.testing.assert_array_equal(a0[key], a1[key])
+            np.testing.assert_array_equal(b0[key], b1[key])
+        for u, v in ((i0, i1), (p0, p1), (j0, j1), (q0, q1)):
+            np.testing.assert_array_equal(u, v)
+        if over:
+            assert (i0 > 0).sum() >= 100              # (first attempts really failed, by the hundred)

@@ -1155,6 +1155,19 @@ def _v_mul_i32_i24(w, ins):
     w.wv32(ins.ops[0], (s24(w.rv32(ins.ops[1])) * s24(w.rv32(ins.ops[2]))).astype(np.int32).astype(np.uint32))
 
 
+def _v_mad_i32_i24(w, ins):
+    def s24(x):
+        v = (x & np.uint32(0xFFFFFF)).astype(np.int64)
+        return np.where(v & 0x800000, v - 0x1000000, v)
+    acc = w.rv32(ins.ops[3]).astype(np.int32).astype(np.int64)
+    w.wv32(ins.ops[0], ((s24(w.rv32(ins.ops[1])) * s24(w.rv32(ins.ops[2])) + acc) & 0xFFFFFFFF).astype(np.uint32))
+
+
+def _v_mad_u32_u24(w, ins):
+    u24 = lambda x: (x & np.uint32(0xFFFFFF)).astype(np.uint64)
+    w.wv32(ins.ops[0], ((u24(w.rv32(ins.ops[1])) * u24(w.rv32(ins.ops[2])) + w.rv32(ins.ops[3]).astype(np.uint64)) & np.uint64(0xFFFFFFFF)).astype(np.uint32))
+
+
 def _v_bfrev(w, ins):
     x = w.rv32(ins.ops[1])
     r = np.zeros(64, dtype=np.uint32)
@@ -1270,6 +1283,8 @@ _PATTERNS = [
     (r"v_(add|sub)_co_u32_e64", _v_addsub_co),
     (r"v_mul_hi_(i32|u32)(_e64)?", _v_mul_hi),
     (r"v_mul_i32_i24(_e32|_e64)?", _v_mul_i32_i24),
+    (r"v_mad_i32_i24", _v_mad_i32_i24),
+    (r"v_mad_u32_u24", _v_mad_u32_u24),
     (r"v_bfrev_b32_e32", _v_bfrev),
     (r"v_cvt_f32_f64_e32", _v_cvt_f32_f64),
     (r"v_cvt_f64_f32_e32", _v_cvt_f64_f32),

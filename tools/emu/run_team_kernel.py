@@ -74,9 +74,11 @@ def private_segment_size(sfile: str, kernel: str) -> int:
 
 
 def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, seed=8, dist="aggressive", csrc=None, inc=None, warm=False,
-            trace=False, max_steps=40_000_000, kind="qp", verbose=True, lds_overlap=True, cfg_over=None, then=None):
+            trace=False, max_steps=40_000_000, kind="qp", verbose=True, lds_overlap=True, cfg_over=None, then=None,
+            inplace=True):
     """cfg_over: nmpc_config fields to override (e.g. qp_polish_passes); then = (file.s, kernel): after a k_team_as workgroup, run workgroup 0 of
-    that k_team_qp_list build on the SAME memory - the second launch of the default path, on the work list the first workgroup left."""
+    that k_team_qp_list build on the SAME memory - the second launch of the default path, on the work list the first workgroup left
+    (with inplace=False: the default, inplace=True, makes k_team_as continue its own failed attempts and leaves the list empty)."""
     from rotors_mpc_controller_amd import _lib
     from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0
     csrc = Path(csrc or ROOT / "rotors_mpc_controller_amd" / "csrc")
@@ -127,7 +129,7 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
     for name, data in ro.items():
         symbols[name] = mem.add(name, np.frombuffer(data, dtype=np.uint8), writable=False)
     # kernel arguments (layout checked against the kernel's metadata: cp 0 | Work 8 | Inputs 120 | Outputs 168 | TeamWork 200 | WorkList 224 | ints 248..)
-    ka = bytearray(288)
+    ka = bytearray(320)
     def put64(off, v): struct.pack_into("<Q", ka, off, v)
     def put32(off, v): struct.pack_into("<i", ka, off, v)
     put64(0, addr["consts"])
@@ -162,8 +164,14 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
     lds_bytes = 4 * stride * 8
     for i, v in enumerate((B, tpw, stride, lstg, base)):
         put32(Sb + 4 * i, v)
-    if kind == "as":                                               # k_team_as: ..., int pass_cap, double *tail_ts
+    # the MODE 2 carve (qp_lds: IP_LM_ROWS doubles per cached stage): the work-list launch, or the continuation inside k_team_as
+    lstg2 = max(0, min(N, (per_team - base - 31) // 88))
+    stride2 = max(carve, base + lstg2 * 88)
+    stride2 += (24 - stride2 % 32 + 32) % 32
+    if kind == "as":                                               # k_team_as: ..., int pass_cap, double *tail_ts, int cont_stride, int cont_lstg
         put32(Sb + 20, 0); put64(Sb + 24, 0)
+        put32(Sb + 32, stride2 if inplace else 0); put32(Sb + 36, lstg2 if inplace else 0)
+        lds_bytes = max(lds_bytes, 4 * stride2 * 8) if inplace else lds_bytes
     kaddr = mem.add("kernarg", np.frombuffer(bytes(ka), dtype=np.uint8), writable=False)
     insts, labels = E.parse_kernel(sfile, kernel)
     w = E.Wave(insts, labels, mem, lds_bytes, kaddr, wg, symbols, max_steps=max_steps)
@@ -182,9 +190,6 @@ def emulate(sfile: str, kernel: str, steps=4, polish=0, share=0, B=256, wg=0, se
     if then is not None and err is None:
         # the work-list launch (launch_split: grid min((B + 3) / 4, 64), LDS carve of qp_lds with IP_LM_ROWS rows per cached stage)
         sfile2, kernel2 = then
-        lstg2 = max(0, min(N, (per_team - base - 31) // 88))
-        stride2 = max(carve, base + lstg2 * 88)
-        stride2 += (24 - stride2 % 32 + 32) % 32
         ka2 = bytearray(512)
         ka2[:248] = ka[:248]
         for i, v in enumerate((B, stride2, lstg2, base)):
