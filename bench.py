@@ -638,7 +638,9 @@ def main() -> None:
         # (tools/rocprof_capture.sh); FETCH_SIZE/WRITE_SIZE are KiB, FETCH_SIZE doubled per the
         # gfx950 note in MI355X_MICROARCH.md.  Only quoted for the configuration it was taken on.
         traffic, traffic_note = None, None
-        split = st.get("ms_tail", 0.0) > 0.0          # default FP64 path: active-set kernel + work-list launch of the general kernel
+        sched = solver.last_schedule()
+        split = sched["split"]                         # default FP64 path: first attempt by k_team_as
+        inplace = sched["inplace"]                     # ... which also continues the attempts that fail (no work-list launch)
         new_qp = args.dtype in ("f64", "f32io") and os.environ.get("NMPC_TEAM_QP", "1") != "0" and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
         kname = ("k_team_as" if split else ("k_team_qp" if new_qp else "k_team_ipm")) if args.mapping == "team" else "k_ipm"
         pmc_file = ROOT / "profiles" / f"latest_{args.mapping}_b{B}_{args.dtype}_pmc_summary.json"
@@ -655,9 +657,9 @@ def main() -> None:
             elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
                 tail = pmc_all.get("k_team_qp_list", pmc_all.get("k_team_ipm_list", {}))
-                if split and "FETCH_SIZE" in tail and "WRITE_SIZE" in tail:      # both launches of a step
+                if split and not inplace and "FETCH_SIZE" in tail and "WRITE_SIZE" in tail:      # both launches of a step
                     traffic += (2.0 * tail["FETCH_SIZE"]["mean"] + tail["WRITE_SIZE"]["mean"]) * 1024.0
-        kernel_name = ("k_team_as + k_team_qp_list" if split else kname) if args.mapping == "team" else "k_ipm"
+        kernel_name = (("k_team_as" if inplace else "k_team_as + k_team_qp_list") if split else kname) if args.mapping == "team" else "k_ipm"
         hbm = dict(achieved=hbm_alg_gbs, peak=HBM_PEAK_GBS, unit="GB/s", frac=hbm_alg_gbs / HBM_PEAK_GBS,
                    algorithmic_bytes_per_solve=alg_b,
                    measured_traffic_gbs=(traffic / kern_s / 1e9 if traffic is not None else None))
@@ -677,7 +679,9 @@ def main() -> None:
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + st.get("ms_tail", 0.0), prepare_ms=st["ms_prepare"],
                       launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=st["ms_tail"],
                                      instances_in_second_launch=st["n_tail"],
-                                     note=("kernel_ms = device time of one step = both launches (HIP events around the timed region)" if N < 160 or os.environ.get("NMPC_BLOCK_TAIL") == "0"
+                                     note=("kernel_ms = device time of one step = the one launch: k_team_as continues the first attempts that fail on the wave that "
+                                           "made them (no work-list launch; instances_in_second_launch counts those continued)" if inplace
+                                           else "kernel_ms = device time of one step = both launches (HIP events around the timed region)" if not sched["tail"]
                                            else "long horizon: k_team_as = preparation + first pass; the second figure is every later launch (block-parallel tail: "
                                                 "k_block_sweep_tail / k_block_scan_tail / k_team_tail per step, then k_team_qp_list on the fallback list); "
                                                 "instances_in_second_launch counts the instances that took an interior-point iteration"))

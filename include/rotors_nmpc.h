@@ -293,6 +293,11 @@ int nmpc_debug_tail_states(nmpc_solver *s, int B, int32_t *host_out);
  * mapped memory does not fault - this is how it shows (tests/test_gpu_parity.py runs the 3-4 integrator-step regression under it). */
 long long nmpc_debug_guard_check(nmpc_solver *s);
 
+/* diagnostic: the launch schedule of the last solve, as bits - 1: first attempt by k_team_as (the default FP64 path; 0: one general kernel),
+ * 2: failed first attempts were continued inside k_team_as (no work-list launch), 4: the block-parallel tail of a long horizon ran.
+ * bench.py names the kernels of its roofline object from it.  Negative: an error code. */
+int nmpc_debug_last_schedule(const nmpc_solver *s);
+
 /* "rotors_nmpc_hip <abi> (gfx950) src <sha1[:12] of the kernel sources the binary was built from>" */
 const char *nmpc_version(void);
 

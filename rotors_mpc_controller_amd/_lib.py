@@ -75,7 +75,7 @@ EXPORTS = (
     "nmpc_last_error", "nmpc_version", "nmpc_abi_sizes", "nmpc_build_hover_reference_device",
     "nmpc_odometry_to_state_device", "nmpc_commands_to_motor_speeds_device", "nmpc_plant_step_device",
     "nmpc_hold_command_device", "nmpc_hold_and_step_device", "nmpc_adjoint_sensitivities_device", "nmpc_kkt_report_device", "nmpc_block_factor_device", "nmpc_debug_factors", "nmpc_debug_tail_states",
-    "nmpc_debug_guard_check",
+    "nmpc_debug_guard_check", "nmpc_debug_last_schedule",
 )
 
 
@@ -184,6 +184,8 @@ def load() -> C.CDLL:
     lib.nmpc_debug_tail_states.restype = C.c_int
     lib.nmpc_debug_guard_check.argtypes = [vp]
     lib.nmpc_debug_guard_check.restype = C.c_longlong
+    lib.nmpc_debug_last_schedule.argtypes = [vp]
+    lib.nmpc_debug_last_schedule.restype = C.c_int
     lib.nmpc_version.argtypes = []
     lib.nmpc_version.restype = C.c_char_p
     lib.nmpc_abi_sizes.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_int)]

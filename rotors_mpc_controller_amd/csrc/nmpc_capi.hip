@@ -143,7 +143,7 @@ struct nmpc_solver {
     bool pack_ready = false;
     uint64_t ws_bytes = 0;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // start | after prepare | after the (first) solve kernel | after the work-list launch
-    bool timed_split = false, last_split = false;
+    bool timed_split = false, last_split = false, last_inplace = false, last_tail = false;
     bool last_shared = false;        // the last solve linearised ONE interval (shared cold start): tAB then holds stage-0 tiles only
     int last_B = 0;
     bool timed = false, timed_fused = false, solved = false;
@@ -502,6 +502,12 @@ void nmpc_destroy(nmpc_solver *s)
 
 const char *nmpc_last_error(const nmpc_solver *s) { return s ? s->err.c_str() : g_create_error.c_str(); }
 
+int nmpc_debug_last_schedule(const nmpc_solver *s)
+{
+    if (!s) return NMPC_EARG;
+    return (s->last_split ? 1 : 0) | ((s->last_split && s->last_inplace) ? 2 : 0) | ((s->last_split && s->last_tail) ? 4 : 0);
+}
+
 // Diagnostics (include/rotors_nmpc.h): bytes of the canary bands around the handle's device buffers that no longer hold the fill
 // pattern; -1 when the handle was created without NMPC_GUARD.  nmpc_last_error() names the first damaged buffer.
 long long nmpc_debug_guard_check(nmpc_solver *s)
@@ -707,6 +713,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     HIP_TRY(s, hipGetLastError());
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
     s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = true; s->last_split = true;
+    s->last_inplace = inplace; s->last_tail = tail;
     s->last_shared = c.shared != 0;
     return 0;
 }

@@ -228,6 +228,12 @@ class NmpcOcpSolver:
             raise RuntimeError(self._lib.nmpc_last_error(self._h).decode())
         return n
 
+    def last_schedule(self) -> dict:
+        """Launch schedule of the last solve (nmpc_debug_last_schedule): first attempt by k_team_as | failed attempts continued in place |
+        block-parallel tail."""
+        v = int(self._lib.nmpc_debug_last_schedule(self._h))
+        return dict(split=bool(v & 1), inplace=bool(v & 2), tail=bool(v & 4))
+
     def stats(self) -> dict:
         st = NmpcStats()
         self._check(self._lib.nmpc_get_stats(self._h, C.byref(st)))
