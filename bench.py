@@ -676,8 +676,8 @@ def main() -> None:
         # figures beside it.  Both sub-objects are always present.
         mfma_path = args.mapping == "team" and args.dtype in ("f64", "f32io") and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
         common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else traffic_note),
-                      kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + st.get("ms_tail", 0.0), prepare_ms=st["ms_prepare"],
-                      launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=st["ms_tail"],
+                      kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + (0.0 if (split and inplace) else st.get("ms_tail", 0.0)), prepare_ms=st["ms_prepare"],
+                      launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=(None if inplace else st["ms_tail"]),
                                      instances_in_second_launch=st["n_tail"],
                                      note=("kernel_ms = device time of one step = the one launch: k_team_as continues the first attempts that fail on the wave that "
                                            "made them (no work-list launch; instances_in_second_launch counts those continued)" if inplace
