@@ -1,6 +1,6 @@
-// nmpc_as.hip -- k_team_as, the active-set kernel of the default FP64 path, built with -mllvm -amdgpu-mfma-vgpr-form (see
-// nmpc_as_launch.hpp for why this is a translation unit of its own; every other kernel of nmpc_team_as.hpp lives in nmpc_qp.hip,
-// built WITHOUT that flag).
+// nmpc_as.hip -- k_team_as, the kernel of the default FP64 path (first active-set attempt of every instance and, on the same wave, the
+// continuation of the attempts that fail), built with the two internal LLVM options of the Makefile (-amdgpu-mfma-vgpr-form,
+// -amdgpu-sched-strategy=iterative-ilp).  nmpc_qp.hip holds the twin built without them, which this build is held bit-equal to.
 #include <hip/hip_runtime.h>
 
 #include "nmpc_as_launch.hpp"

@@ -1,7 +1,7 @@
-// nmpc_as_launch.hpp -- host-side hand-over between the C ABI (nmpc_capi.hip) and the two translation units that hold the kernels of
-// nmpc_team_as.hpp: nmpc_as.hip (k_team_as built with -mllvm -amdgpu-mfma-vgpr-form: MFMA results in the vector registers the
-// following VALU reads, +7 % on that kernel) and nmpc_qp.hip (everything else, default code generation - the flag is an internal
-// option, validated for that one kernel only: see nmpc_qp.hip).
+// nmpc_as_launch.hpp -- host-side hand-over between the C ABI (nmpc_capi.hip) and the translation units that hold the kernels of
+// nmpc_team_as.hpp: nmpc_as.hip (k_team_as) and nmpc_qpf.hip (k_team_qp, k_team_qp_list, k_team_tail) - what runs, built with the internal
+// LLVM options of the Makefile - and nmpc_qp.hip (all four, default code generation: the twins the flag builds are held bit-equal to, and
+// what sim_num_steps > 2 runs).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -34,7 +34,7 @@ int launch_team_as(const AsLaunch &a, const Inputs<float> &in, const Outputs<flo
 // enqueue a kernel of nmpc_qp.hip: k_team_as (kind 0), k_team_qp (1), k_team_qp_list (2)
 int launch_team_qp(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
 int launch_team_qp(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
-// k_team_qp (kind 1) of nmpc_qpf.hip: the same source built with -amdgpu-mfma-vgpr-form
+// kinds 1-3 of nmpc_qpf.hip: the same source built with the Makefile's internal LLVM options
 int launch_team_qp_flag(const AsLaunch &a, const Inputs<double> &in, const Outputs<double> &out);
 int launch_team_qp_flag(const AsLaunch &a, const Inputs<float> &in, const Outputs<float> &out);
 
