@@ -575,8 +575,8 @@ def test_flag_build_of_the_interior_point_kernel_is_bit_equal_to_the_default_cod
         assert i0.max() >= 3                      # (interior-point iterations really ran)
 
 
-@pytest.mark.parametrize("share,traj", [(1, False), (1, True), (0, True), (0, False)])
-def test_continuing_failed_attempts_inside_k_team_as_gives_the_bits_of_the_work_list_launch(share, traj, monkeypatch):
+@pytest.mark.parametrize("share,traj,dtype", [(1, False, "f64"), (1, True, "f64"), (0, True, "f64"), (0, False, "f64"), (1, True, "f32io"), (0, True, "f32io")])
+def test_continuing_failed_attempts_inside_k_team_as_gives_the_bits_of_the_work_list_launch(share, traj, dtype, monkeypatch):
     """Default since round 4: a team whose first active-set attempt fails is continued at once by the wave that made the attempt (team_as MODE 2
     inside k_team_as) instead of being appended to a work list for a second launch (NMPC_TEAM_INPLACE=0; the per-stage build without
     trajectories and long horizons keep the list).  Which wave continues an instance, and beside which wave-mates, must not show in a
@@ -588,7 +588,7 @@ def test_continuing_failed_attempts_inside_k_team_as_gives_the_bits_of_the_work_
         res = []
         for inplace in ("1", "0"):
             monkeypatch.setenv("NMPC_TEAM_INPLACE", inplace)
-            s = make_solver(max_batch=len(x0), flags=_lib.FLAG_TEAM_MAPPING | share, **over)
+            s = make_solver(max_batch=len(x0), flags=_lib.FLAG_TEAM_MAPPING | share, dtype=_lib.DTYPE_F32IO if dtype == "f32io" else _lib.DTYPE_F64, **over)
             a = s.solve_batch(x0, yref, ye, want_traj=traj)
             ia, pa = s.iterations(), s.passes()
             xi, ui = (a["x"], a["u"]) if traj else (None, None)
