@@ -119,6 +119,8 @@ struct nmpc_solver {
     double *d_gbase = nullptr;       // growth certificate: first-factorisation value per instance (active-set kernel -> work-list launch)
     void *d_consts = nullptr;        // Consts<double> in device memory (the active-set kernel reads it from there)
     int team_split = 1;              // active-set kernel + work-list launch (default); NMPC_TEAM_SPLIT=0: one general kernel
+    int list_grid = 256;             // workgroups of the work-list launch (NMPC_LIST_GRID; each strides over the list.  64 until round 4: a list of
+                                     // 1500 instances then took 1.97 ms against 0.93 with 256, and an empty list costs the same either way)
     int team_inplace = 1;            // a failed first attempt continues on its own wave inside k_team_as (no work-list launch); NMPC_TEAM_INPLACE=0:
                                      // work list + k_team_qp_list (always so for long horizons - the block-parallel tail - and the 256-register builds)
     int as_noflag = 0;               // NMPC_AS_NOFLAG=1: k_team_as from nmpc_qp.hip (default code generation) instead of nmpc_as.hip
@@ -399,6 +401,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_INPLACE")) s->team_inplace = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_LIST_GRID")) s->list_grid = std::max(1, std::min(4096, std::atoi(e)));
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LDS_OVERLAP")) s->lds_overlap = std::atoi(e) != 0;
@@ -589,7 +592,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);
     WorkList wl;
     wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
-    const int nlist = std::min((B + 3) / 4, 64);      // usually empty: keep the launch small (each workgroup strides over the list)
+    const int nlist = std::min((B + 3) / 4, s->list_grid);      // usually empty: keep the launch small (each workgroup strides over the list)
     const bool traj = out.x_out != nullptr || out.u_out != nullptr;
     const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
     int occ_as = s->team_occ;
