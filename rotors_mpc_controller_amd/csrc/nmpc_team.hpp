@@ -1591,7 +1591,10 @@ __device__ __forceinline__ void jac_coef(const Consts<T> &c, int r, JacCoef<T> &
 {
     const int ta = r >> 2, tc = r & 3;
     NMPC_UNROLL for (int i = 0; i < 4; i++) { k.vq[i] = (T)NMPC_TVQ[r][i]; k.qw[i] = T(0.5) * (T)NMPC_TQW[r][i]; }
-    const T kx = -(c.J[2] - c.J[1]) * c.invJ[0], ky = -(c.J[0] - c.J[2]) * c.invJ[1], kz = -(c.J[1] - c.J[0]) * c.invJ[2];
+    T kx = -(c.J[2] - c.J[1]) * c.invJ[0], ky = -(c.J[0] - c.J[2]) * c.invJ[1], kz = -(c.J[1] - c.J[0]) * c.invJ[2];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+v"(kx), "+v"(ky), "+v"(kz));      // three values and two selects - left alone, the compiler builds an if / else per lane
+#endif
     const T kc = tc == 0 ? kx : (tc == 1 ? ky : kz);
     NMPC_UNROLL for (int i = 0; i < 3; i++) { k.qq[i] = T(0.5) * (T)NMPC_TQQ[r][i]; k.ww[i] = kc * (T)NMPC_TWW[r][i]; }
     T fu = 0;

@@ -64,11 +64,13 @@ constexpr int TEAM_AS_LDS_SHARED = A_EV + AS_EV;            // 368
 constexpr int TEAM_AS_LDS_STAGE = A_EV + AS_CH * AS_EV;     // 760
 
 // Which builds of k_team_as carry the continuation of failed first attempts (team_as_kernel below; host and device agree through this one
-// function).  Not the per-stage build without trajectories: with the continuation inlined, the iterative-ilp build of THAT kernel parks a
-// live value in an accumulation register in front of the EXEC restore of a join block (tools/emu/exec_join_check.py finds the pattern,
-// tests/test_isa_emulation.py runs it on every flag build) - a code-generation fault of the scheduler strategy, so that kernel keeps the
-// work-list launch, which compiles clean.
-constexpr bool as_cont_built(bool shared, bool traj) { return shared || traj; }
+// function): all of the one-wave builds.  A switch per variant because the translation units that run are built with
+// -amdgpu-sched-strategy=iterative-ilp, and that strategy has produced ONE kernel - the per-stage build without trajectories, with the
+// continuation inlined - in which a register-parking copy sat in front of the EXEC restore of a join block.
+// tools/emu/exec_join_check.py finds the pattern and tests/test_isa_emulation.py runs it on every flag build; that kernel compiled clean
+// once jac_coef's selects stopped being an if / else (nmpc_team.hpp).  Should the check ever fail again for a variant, returning false for
+// it here gives it back the work-list launch, whose code is unchanged.
+constexpr bool as_cont_built(bool shared, bool traj) { (void)shared; (void)traj; return true; }
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
 

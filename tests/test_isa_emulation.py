@@ -78,7 +78,7 @@ def test_shipped_flag_build_of_the_interior_point_kernel():
     _check(s, "k_team_qpILb1ELb0EdEE", range(0, 2), steps=2, polish=0, share=1, B=2048, dist="near_hover", seed=0, kind="qp")
 
 
-def _check_hand_over(as_kernel, list_kernel, wgs, warm):
+def _check_hand_over(as_kernel, list_kernel, wgs, warm, share=1):
     """Failed first attempts continued (pass budget of ONE pass per attempt, so that every instance that pins an input fails its first attempt):
     list_kernel = None - inside k_team_as, on the wave that made the attempt (what runs by default); else the work-list flow - k_team_as with
     the continuation switched off, then workgroup 0 of that k_team_qp_list build on the memory it left.  Addresses of the instruction
@@ -89,7 +89,7 @@ def _check_hand_over(as_kernel, list_kernel, wgs, warm):
     over = dict(qp_polish_passes=1, qp_polish_budget=2)
     continued = 0
     for wg in wgs:
-        r = R.emulate(_asm("nmpc_as.s"), as_kernel, wg=wg, verbose=False, steps=2, polish=1, share=1, B=2048, dist="aggressive", seed=1, kind="as",
+        r = R.emulate(_asm("nmpc_as.s"), as_kernel, wg=wg, verbose=False, steps=2, polish=1, share=share, B=2048, dist="aggressive", seed=1, kind="as",
                       warm=warm, cfg_over=over, inplace=list_kernel is None,
                       then=None if list_kernel is None else (_asm("nmpc_qpf.s"), list_kernel))
         runs = [r] if list_kernel is None else [r, r["second"]]
@@ -117,10 +117,11 @@ def test_shipped_flag_build_continues_failed_first_attempts_inside_k_team_as():
     iterations and a second attempt - in one instruction stream (the default schedule of short horizons: no work-list launch)."""
     _check_hand_over("k_team_asILb1ELb0ELi1EdEE", None, range(0, 2), warm=False)
     _check_hand_over("k_team_asILb0ELb1ELi1EdEE", None, range(0, 2), warm=True)
+    _check_hand_over("k_team_asILb0ELb0ELi1EdEE", None, range(1, 3), warm=False, share=0)     # (the kernel of DESIGN.md section 4.2a's fault)
 
 
 def test_shipped_flag_builds_of_both_launches_with_instances_handed_over():
-    """The work-list flow (long horizons, NMPC_TEAM_INPLACE=0, the per-stage build without trajectories): k_team_as<shared> ->
+    """The work-list flow (long horizons, NMPC_TEAM_INPLACE=0): k_team_as<shared> ->
     k_team_qp_list<shared> (nmpc_qpf.hip)."""
     _check_hand_over("k_team_asILb1ELb0ELi1EdEE", "k_team_qp_listILb1ELb0EdEE", range(0, 2), warm=False)
 
