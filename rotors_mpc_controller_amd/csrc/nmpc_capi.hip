@@ -596,12 +596,13 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     const bool traj = out.x_out != nullptr || out.u_out != nullptr;
     const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
     int occ_as = s->team_occ;
-    // Two waves per SIMD (256 registers, no LDS stage cache) pay only where one wave per SIMD would leave a second,
-    // part-filled round: between 1024 and 2048 waves (B = 6144: 50.6 against 48.3 M solves/s, B = 8192: 63.8 / 62.7).
-    // From 3072 waves up the one-wave build with its stage cache wins (B = 12288: 74.0 / 69.2, B = 65536: 93.8 / 91.4).
-    // The per-stage variant spills inside its sweeps at 256 registers and never takes the two-wave build.
+    // Two waves per SIMD (256 registers, no LDS stage cache) pay only where one wave per SIMD would leave a small second round: just
+    // above 1024 waves.  Re-measured on the round-4 builds (profiles/r04v_occupancy_sweep.txt; two-wave / one-wave build, M solves/s):
+    // B = 4608 51.8 / 49.4, B = 5120 56.7 / 54.5, B = 6144 49.7 / 51.4, B = 7168 67.8 / 82.0, B = 8192 57.8 / 67.4, B = 16384 69.5 / 82.8,
+    // B = 65536 84.4 / 94.9 - the one-wave build gained more from the scheduler strategy, and the range that was (1024, 2048] waves until
+    // round 4 cost 15-20 % at its upper end.  The per-stage variant spills at 256 registers and never takes the two-wave build.
     const int nwaves = (B + tpw - 1) / tpw;
-    if (occ_as == 0) occ_as = (nwaves > 1024 && nwaves <= 2048) ? 2 : 1;
+    if (occ_as == 0) occ_as = (nwaves > 1024 && nwaves <= 1408) ? 2 : 1;
     if (!c.shared) occ_as = 1;
     // LDS stage cache: what is left of the CU's 160 KB at this occupancy (40 KB per wave at one wave per SIMD) holds the
     // factors of the first stages; the team stride stays 192 B past a multiple of the 256-B bank row (24 doubles mod 32).

@@ -202,11 +202,11 @@ def test_hold_and_step_equals_hold_then_plant_step():
 
 
 def test_two_waves_per_simd_build_equals_the_one_wave_build():
-    """Between 1024 and 2048 waves the active-set kernel runs its two-waves-per-SIMD build (256 registers, no LDS stage
-    cache); everything else runs the one-wave build.  Same arithmetic: a batch of 6144 (1536 waves) must reproduce, bit
-    for bit, the same instances solved as two batches of 3072 (768 waves each), trajectories included, and a sample
+    """Just above 1024 waves (up to 1408: nmpc_capi.hip, launch_split) the active-set kernel runs its two-waves-per-SIMD build (256
+    registers, no LDS stage cache); everything else runs the one-wave build.  Same arithmetic: a batch of 5120 (1280 waves) must
+    reproduce, bit for bit, the same instances solved as two batches of 2560 (640 waves each), trajectories included, and a sample
     must agree with the oracle."""
-    B = 6144
+    B, H = 5120, 2560
     s = make_solver(max_batch=B)
     x0 = np.concatenate([sample_x0(B - 1024, 21, **NEAR_HOVER), sample_x0(1024, 22, **AGGRESSIVE)])
     x0 = x0[np.random.default_rng(5).permutation(B)]
@@ -215,9 +215,9 @@ def test_two_waves_per_simd_build_equals_the_one_wave_build():
     big = s.solve_batch(x0, yref, ye, want_traj=True)
     assert (big["status"] == 0).all()
     for h in range(2):
-        part = s.solve_batch(x0[h * 3072:(h + 1) * 3072], yref, ye, want_traj=True)
+        part = s.solve_batch(x0[h * H:(h + 1) * H], yref, ye, want_traj=True)
         for key in ("u0", "status", "x", "u"):
-            np.testing.assert_array_equal(big[key][h * 3072:(h + 1) * 3072], part[key])
+            np.testing.assert_array_equal(big[key][h * H:(h + 1) * H], part[key])
     c = O.default_config(qp_gamma=0.0, qp_polish=1)
     idx = np.random.default_rng(6).choice(B, 256, replace=False)
     ref = O.solve_batch(c, x0[idx], *O.hover_yref(c), nthreads=8)
