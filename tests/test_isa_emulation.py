@@ -151,6 +151,19 @@ def test_the_configuration_that_faulted_in_round_3_on_the_flag_build_of_k_team_q
     _check(s, "k_team_qpILb0ELb1EdEE", range(0, 4), steps=4, polish=0, share=0, B=256, dist="aggressive", seed=8, kind="qp", warm=True)
 
 
+def test_mfma_results_are_read_no_earlier_than_the_hazard_table_allows_in_the_flag_builds():
+    """tools/emu/isa_checks.py: for every v_mfma_f64_4x4x4 that writes vector registers (all of them in the flag builds), the distance in
+    wait states to the first reader / overwriter along every path, against LLVM's table for the DGEMM 4x4x4 result (VALU 6, memory 9,
+    MFMA A/B 6).  The scheduler strategy moves instructions into those slots; the hazard recognizer pads what is left - nothing may be
+    closer than the table."""
+    import isa_checks as H
+    for target, kernels in (("nmpc_as.s", ("k_team_asILb1ELb0ELi1EdEE", "k_team_asILb0ELb1ELi1EdEE")), ("nmpc_qpf.s", ("k_team_qpILb1ELb0EdEE",)),
+                            ("nmpc_blockf.s", (None,))):
+        for k in kernels:
+            found = H.check(_asm(target), k, verbose=False)
+            assert not found, (target, k, found[:3])
+
+
 def _run_snippet(tmp_path, body, scratch_bytes=0):
     """Emulate a hand-written instruction sequence: s[0:1] = address of a 64-byte read-only block holding the double 2.5 at offset 8,
     s[2:3] = address of a 512-byte output buffer."""
