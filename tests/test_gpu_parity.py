@@ -590,6 +590,7 @@ def test_continuing_failed_attempts_inside_k_team_as_gives_the_bits_of_the_work_
             monkeypatch.setenv("NMPC_TEAM_INPLACE", inplace)
             s = make_solver(max_batch=len(x0), flags=_lib.FLAG_TEAM_MAPPING | share, dtype=_lib.DTYPE_F32IO if dtype == "f32io" else _lib.DTYPE_F64, **over)
             a = s.solve_batch(x0, yref, ye, want_traj=traj)
+            assert s.last_schedule() == dict(split=True, inplace=inplace == "1", tail=False)      # (nmpc_debug_last_schedule: what ran)
             ia, pa = s.iterations(), s.passes()
             xi, ui = (a["x"], a["u"]) if traj else (None, None)
             if xi is None:
