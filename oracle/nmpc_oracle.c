@@ -21,6 +21,10 @@
 
 #define ORC_WARM_DELTA 1e-3   /* warm start of the interior point from a failed attempt: distance from the bounds / box width */
 #define ORC_WARM_MU 1e-3      /* ... and the central-path value that floors its multipliers */
+/* bound residuals u - lo - t_l, hi - u - t_u of the interior point's iterate enter its Newton system (HPIPM's res_d); 0: left out */
+#ifndef ORC_BOUND_RESIDUAL
+#define ORC_BOUND_RESIDUAL 1
+#endif
 #define NX ORC_NX
 #define NU ORC_NU
 #define NY ORC_NY
@@ -32,7 +36,12 @@
  * batch loop (single solves, the tests' direct calls) no arena is installed and these are malloc / free.  Not a change of the
  * arithmetic: only where the same arrays live.  (The sanitizer build keeps the heap, so ASan still sees every array.)          */
 typedef struct { char *base; size_t cap, off, need; } orc_arena;
-#if defined(__SANITIZE_ADDRESS__)
+#if defined(__has_feature)
+#if __has_feature(address_sanitizer)
+#define ORC_ASAN_CLANG 1
+#endif
+#endif
+#if defined(__SANITIZE_ADDRESS__) || defined(ORC_ASAN_CLANG)    /* gcc | clang spelling of "built with -fsanitize=address" */
 #define ORC_USE_ARENA 0
 #else
 #define ORC_USE_ARENA 1
@@ -111,6 +120,7 @@ void orc_default_config(orc_config *c)
     c->qp_tol_step = 1e-3;
     c->qp_maxiter_status = 0;
     c->qp_warm_start = 1;
+    c->qp_exit_mode = 0;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -555,9 +565,10 @@ static void riccati_forward(const ocpqp *p, const ricc_fact *f, const double *dx
  * An accepted point is THE solution of the strictly convex QP; a rejected one costs one sweep and the
  * IPM simply continues.  Returns 1 if accepted (u, x overwritten; ll, lu set to the multipliers).    */
 static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, double **u, double **ll,
-                        double **lu, double *x, int max_pass, int *passes, double growth_max, double *gbase,
-                        double *growth, int *untrusted, int *warm)
+                        double **lu, double **tlo, double **tup, double *x, int max_pass, int *passes, double growth_max,
+                        double *gbase, double *growth, int *untrusted, int *warm)
 {
+    /* tlo, tup: the slacks the interior point carries (ocpqp_ipm); the active-set guess compares a multiplier with ITS slack */
     /* warm (nullable): out, 1 when the attempt ran out of passes and (u, ll, lu) were replaced by the warm start built from its
      * last pass (the pass must have had pins: a pass from "all free" that fails leaves nothing to build on)                    */
     int exhausted = 0;
@@ -589,7 +600,7 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         memcpy(m.R[k], p->R[k], sizeof(double) * nu * nu); memcpy(m.S[k], p->S[k], sizeof(double) * nu * NX);
         memcpy(m.q[k], p->q[k], sizeof(double) * NX); memcpy(m.r[k], p->r[k], sizeof(double) * nu);
         for (int i = 0; i < nu; i++) {
-            const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
+            const double tl = tlo[k][i], tu = tup[k][i];
             pin[k][i] = ll[k][i] > tl ? -1 : (lu[k][i] > tu ? 1 : 0);
         }
         for (int i = 0; i < nu; i++) {
@@ -699,8 +710,10 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
                 if (v < lo + tl) v = lo + tl;
                 if (v > hi - th) v = hi - th;
                 u[k][i] = v;
-                ll[k][i] = ORC_WARM_MU / (v - lo);
-                lu[k][i] = ORC_WARM_MU / (hi - v);
+                tlo[k][i] = v - lo;
+                tup[k][i] = hi - v;
+                ll[k][i] = ORC_WARM_MU / tlo[k][i];
+                lu[k][i] = ORC_WARM_MU / tup[k][i];
             }
     }
     if (ok) {
@@ -725,11 +738,76 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
 
 /* [UPSTREAM] HPIPM-style Mehrotra predictor-corrector interior point method on the
  * OCP-QP, Riccati factorisation of the KKT system, cold-started every call (U9).
- * Feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
- * states are implied by the (affine) dynamics, so the only residuals are stationarity
+ * The slacks of the input bounds are ITERATES of their own, as in HPIPM (d_ocp_qp_ipm: v, pi, lam, t): t_l, t_u start at
+ * u - lo, hi - u and are updated t <- t + alpha dt with dt from the linearised bound equations, dt_l = du + (u - lo - t_l),
+ * dt_u = -du + (hi - u - t_u); the bound residuals in the brackets (HPIPM's res_d) are zero to rounding and enter the
+ * right-hand side of the Newton system like any other residual.  A slack is never formed as the difference u - lo of two
+ * numbers of magnitude 1-10 again: at mu <= 1e-11 with a multiplier in the thousands the central path puts it at 1e-14,
+ * below the resolution of that difference (round 4: 13 fuzz instances ended NaN here because u - lo rounded to 0).
+ * States are implied by the (affine) dynamics, so the residuals that matter are stationarity
  * (scales by 1-alpha per step; tracked as rho) and complementarity (mu).                */
+/* states of the QP from its inputs (the dynamics are affine): x_0 = dx0, x_{k+1} = A x + B u + b */
+static void ipm_rollout(const ocpqp *p, const double *dx0, double **u, double *x)
+{
+    const int N = p->N;
+    for (int i = 0; i < NX; i++) x[i] = dx0 ? dx0[i] : 0.0;
+    for (int k = 0; k < N; k++)
+        for (int i = 0; i < NX; i++) {
+            double s = p->b[k][i];
+            for (int j = 0; j < NX; j++) s += p->A[k][i * NX + j] * x[k * NX + j];
+            for (int j = 0; j < p->nu[k]; j++) s += p->B[k][i * p->nu[k] + j] * u[k][j];
+            x[(k + 1) * NX + i] = s;
+        }
+}
+
+/* TRUE residuals of a primal-dual point, recomputed from scratch in the infinity norm: stationarity of the inputs (costates by
+ * the adjoint recursion from the rolled-out states), complementarity max lam * slack, bound equations max |u - lo - t_l|,
+ * |hi - u - t_u|.  tlo / tup NULL: slacks taken as u - lo, hi - u (an accepted active-set solution carries none).  xin NULL:
+ * the states are rolled out here (x is then scratch of (N+1)*NX doubles allocated inside).                                   */
+static void ipm_true_residuals(const ocpqp *p, const double *dx0, double **u, double **ll, double **lu, double **tlo, double **tup,
+                               const double *xin, double *res_stat, double *res_comp, double *res_bnd)
+{
+    const int N = p->N;
+    double *xs = NULL;
+    if (!xin) { xs = dalloc((size_t)(N + 1) * NX); ipm_rollout(p, dx0, u, xs); }
+    const double *x = xin ? xin : xs;
+    double pi[NX], pin[NX], rs = 0.0, rc = 0.0, rb = 0.0;
+    for (int i = 0; i < NX; i++) {
+        double s = p->qN[i];
+        for (int j = 0; j < NX; j++) s += p->QN[i * NX + j] * x[N * NX + j];
+        pi[i] = s;
+    }
+    for (int k = N - 1; k >= 0; k--) {
+        const int m = p->nu[k];
+        for (int i = 0; i < m; i++) {
+            double s = p->r[k][i] - ll[k][i] + lu[k][i];
+            for (int j = 0; j < m; j++) s += p->R[k][i * m + j] * u[k][j];
+            for (int j = 0; j < NX; j++) s += p->S[k][i * NX + j] * x[k * NX + j];
+            for (int j = 0; j < NX; j++) s += p->B[k][j * m + i] * pi[j];
+            if (fabs(s) > rs) rs = fabs(s);
+            const double sl = u[k][i] - p->lo[k][i], su = p->hi[k][i] - u[k][i];
+            const double tl = tlo ? tlo[k][i] : sl, tu = tup ? tup[k][i] : su;
+            const double c1 = ll[k][i] * tl, c2 = lu[k][i] * tu;
+            if (c1 > rc) rc = c1;
+            if (c2 > rc) rc = c2;
+            if (fabs(sl - tl) > rb) rb = fabs(sl - tl);
+            if (fabs(su - tu) > rb) rb = fabs(su - tu);
+        }
+        for (int i = 0; i < NX; i++) {
+            double s = p->q[k][i];
+            for (int j = 0; j < NX; j++) s += p->Q[k][i * NX + j] * x[k * NX + j];
+            for (int j = 0; j < m; j++) s += p->S[k][j * NX + i] * u[k][j];
+            for (int j = 0; j < NX; j++) s += p->A[k][j * NX + i] * pi[j];
+            pin[i] = s;
+        }
+        memcpy(pi, pin, sizeof(pi));
+    }
+    if (xs) orc_free(xs);
+    *res_stat = rs; *res_comp = rc; *res_bnd = rb;
+}
+
 /* standard (cold) start point of the interior-point iteration: inputs pushed inside the box, multipliers on the central path of mu0 */
-static void ipm_cold_point(const orc_config *c, const ocpqp *p, double **u, double **ll, double **lu)
+static void ipm_cold_point(const orc_config *c, const ocpqp *p, double **u, double **ll, double **lu, double **tlo, double **tup)
 {
     for (int k = 0; k < p->N; k++)
         for (int i = 0; i < p->nu[k]; i++) {
@@ -741,8 +819,10 @@ static void ipm_cold_point(const orc_config *c, const ocpqp *p, double **u, doub
             if (v - lo < thr) v = lo + thr;
             if (hi - v < thr) v = hi - thr;
             u[k][i] = v;
-            ll[k][i] = c->qp_mu0 / (v - lo);
-            lu[k][i] = c->qp_mu0 / (hi - v);
+            tlo[k][i] = v - lo;
+            tup[k][i] = hi - v;
+            ll[k][i] = c->qp_mu0 / tlo[k][i];
+            lu[k][i] = c->qp_mu0 / tup[k][i];
         }
 }
 
@@ -760,33 +840,52 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     double **sig = (double **)orc_malloc(sizeof(double *) * N), **rh = (double **)orc_malloc(sizeof(double *) * N);
     double **ua = (double **)orc_malloc(sizeof(double *) * N), **du = (double **)orc_malloc(sizeof(double *) * N);
     double **dla = (double **)orc_malloc(sizeof(double *) * N), **dua = (double **)orc_malloc(sizeof(double *) * N);
+    /* slacks of the input bounds (iterates), their directions, and the bound residuals of the iteration in flight */
+    double **tlo = (double **)orc_malloc(sizeof(double *) * N), **tup = (double **)orc_malloc(sizeof(double *) * N);
+    double **dtl = (double **)orc_malloc(sizeof(double *) * N), **dtu = (double **)orc_malloc(sizeof(double *) * N);
+    double **rbl = (double **)orc_malloc(sizeof(double *) * N), **rbu = (double **)orc_malloc(sizeof(double *) * N);
     double *xh = dalloc((size_t)(N + 1) * NX);
+    double **bsh = (double **)orc_malloc(sizeof(double *) * N);     /* b_k + B_k u_k of the iterate (input-delta form of the Newton system) */
+    double **qsh = (double **)orc_malloc(sizeof(double *) * N);     /* q_k + S_k' u_k (the cross term of a condensed stage) */
+    ocpqp ps = *p;
+    ps.b = bsh; ps.q = qsh;
     for (int k = 0; k < N; k++) {
         const int m = p->nu[k];
         nc += 2 * m;
+        bsh[k] = dalloc(NX); qsh[k] = dalloc(NX);
         f.L[k] = dalloc((size_t)m * m); f.M[k] = dalloc((size_t)m * NX); f.m[k] = dalloc(m);
         ll[k] = dalloc(m); lu[k] = dalloc(m); sig[k] = dalloc(m); rh[k] = dalloc(m);
         ua[k] = dalloc(m); du[k] = dalloc(m); dla[k] = dalloc(m); dua[k] = dalloc(m);
+        tlo[k] = dalloc(m); tup[k] = dalloc(m); dtl[k] = dalloc(m); dtu[k] = dalloc(m); rbl[k] = dalloc(m); rbu[k] = dalloc(m);
     }
-    ipm_cold_point(c, p, u, ll, lu);
+    ipm_cold_point(c, p, u, ll, lu, tlo, tup);
     double rho = 1.0, mu = 0.0, pol_mu = c->qp_polish_mu;
     double gbase = 0.0, growth = 0.0, step_last = 0.0;
     int polished = 0, npolish = 0, untrusted = 0;
     int warm_derived = 0;   /* the iterate descends from a warm start (an exhausted attempt's last pass), not from the cold point */
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
+    /* [UPSTREAM U9] exit of HPIPM at its DEFAULT tolerances (qp_exit_mode = 1; acados leaves res_g/b/d/m_max at 1e-8 and
+     * controller.py:179-190 sets none): all four TRUE residuals of the iterate - stationarity, dynamics (0 here: the states
+     * are implied), bounds (|u - lo - t|), complementarity (max lam t, as HPIPM's res_m with mu = 0) - at most qp_tol_stat /
+     * qp_tol_comp in the infinity norm.  Used to PREDICT acados' own accuracy floor (tests/test_acados_floor.py), not by
+     * the shipped defaults (mode 0: mean complementarity + stationarity factor, far tighter tolerances).                */
     for (;;) {
         mu = 0.0;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++)
-                mu += ll[k][i] * (u[k][i] - p->lo[k][i]) + lu[k][i] * (p->hi[k][i] - u[k][i]);
+                mu += ll[k][i] * tlo[k][i] + lu[k][i] * tup[k][i];
         mu /= nc;
         if (!(mu == mu)) { status = 1; break; }
-        if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat && (it == 0 || !(c->qp_tol_step > 0.0) || step_last <= c->qp_tol_step)) break;
+        if (c->qp_exit_mode == 1) {
+            double rs = 0.0, rc = 0.0, rb = 0.0;
+            ipm_true_residuals(p, dx0, u, ll, lu, tlo, tup, NULL, &rs, &rc, &rb);
+            if (rs <= c->qp_tol_stat && rc <= c->qp_tol_comp && rb <= c->qp_tol_stat) break;
+        } else if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat && (it == 0 || !(c->qp_tol_step > 0.0) || step_last <= c->qp_tol_step)) break;
         if (c->qp_polish && mu <= pol_mu && npolish < c->qp_polish_budget) {
             int trip = 0, warm = 0;
             /* the warm start is for the iteration BETWEEN two attempts: an attempt that uses up the budget leaves the iterate alone */
             const int last_attempt = npolish + c->qp_polish_passes >= c->qp_polish_budget;
-            if (ocpqp_polish(p, dx0, &f, u, ll, lu, x, c->qp_polish_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip,
+            if (ocpqp_polish(p, dx0, &f, u, ll, lu, tlo, tup, x, c->qp_polish_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip,
                              (c->qp_warm_start && !last_attempt) ? &warm : NULL)) {
                 polished = 1; mu = 0.0; rho = 0.0; break;
             }
@@ -796,7 +895,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 mu = 0.0;
                 for (int k = 0; k < N; k++)
                     for (int i = 0; i < p->nu[k]; i++)
-                        mu += ll[k][i] * (u[k][i] - p->lo[k][i]) + lu[k][i] * (p->hi[k][i] - u[k][i]);
+                        mu += ll[k][i] * tlo[k][i] + lu[k][i] * tup[k][i];
                 mu /= nc;
                 rho = 1.0;
                 warm_derived = 1;
@@ -806,7 +905,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 /* no attempt is left and the iterate in hand descends from a warm start - off the central path, a poor place to
                  * converge from (42 iterations and 1e-6 of accuracy on fuzz draw 353, against 15 and 2e-8): the interior point
                  * finishes the QP from its standard cold point                                                                */
-                ipm_cold_point(c, p, u, ll, lu);
+                ipm_cold_point(c, p, u, ll, lu, tlo, tup);
                 mu = c->qp_mu0;
                 rho = 1.0;
                 warm_derived = 0;
@@ -814,16 +913,36 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         }
         if (it >= itmax) { status = 2; break; }
         it++;
-        /* predictor (affine scaling) */
-        for (int k = 0; k < N; k++)
-            for (int i = 0; i < p->nu[k]; i++) {
-                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                sig[k][i] = ll[k][i] / tl + lu[k][i] / tu;
-                rh[k][i] = p->r[k][i] - sig[k][i] * u[k][i];
+        /* predictor (affine scaling), solved for the STEP of the inputs: with u = u_it + w the stage reads x+ = A x + B w +
+         * (b + B u_it), input gradient r + R u_it, state gradient q + S'u_it, input Hessian R + sig - states stay absolute, inputs become deltas.  The
+         * target form of rounds 1-4 (solve for ua, then d = ua - u) loses everything of d below ulp(u), and a slack carried to
+         * 1e-14 needs its direction to that accuracy: the step of a nearly active input is d ~ -t, formed here as
+         * gradient / (R + sig) without a cancellation.  Bound residuals of the iterate (HPIPM's res_d; the start is feasible
+         * and t follows u exactly in exact arithmetic, so they hold rounding of size ulp(u)) stay fixed over the iteration and
+         * enter the affine right-hand side, so that the step restores u - lo = t_l, hi - u = t_u as far as u can resolve it */
+        for (int k = 0; k < N; k++) {
+            const int m = p->nu[k];
+            for (int i = 0; i < NX; i++) {
+                double s2 = p->b[k][i];
+                for (int j = 0; j < m; j++) s2 += p->B[k][i * m + j] * u[k][j];
+                bsh[k][i] = s2;
+                double s3 = p->q[k][i];
+                for (int j = 0; j < m; j++) s3 += p->S[k][j * NX + i] * u[k][j];
+                qsh[k][i] = s3;
             }
+            for (int i = 0; i < m; i++) {
+                const double tl = tlo[k][i], tu = tup[k][i];
+                rbl[k][i] = ORC_BOUND_RESIDUAL ? (u[k][i] - p->lo[k][i]) - tl : 0.0;
+                rbu[k][i] = ORC_BOUND_RESIDUAL ? (p->hi[k][i] - u[k][i]) - tu : 0.0;
+                sig[k][i] = ll[k][i] / tl + lu[k][i] / tu;
+                double s2 = p->r[k][i];
+                for (int j = 0; j < m; j++) s2 += p->R[k][i * m + j] * u[k][j];
+                rh[k][i] = s2 + ll[k][i] / tl * rbl[k][i] - lu[k][i] / tu * rbu[k][i];
+            }
+        }
         {
             double g = 0.0;
-            const int fail = riccati_backward(p, sig, rh, 0, 1, &f, &g);
+            const int fail = riccati_backward(&ps, sig, rh, 0, 1, &f, &g);
             if (!fail && gbase == 0.0) gbase = g;
             if (!fail && gbase > 0.0 && g / gbase > growth) growth = g / gbase;
             const int trip = !fail && c->qp_growth_max > 0.0 && !(g <= c->qp_growth_max * gbase);
@@ -835,26 +954,28 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 break;
             }
         }
-        riccati_forward(p, &f, dx0, 0, ua, xh);
+        riccati_forward(&ps, &f, dx0, 0, ua, xh);      /* ua: the affine STEP of the inputs */
         double aaff = 1.0;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
-                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                const double d = ua[k][i] - u[k][i];
-                dla[k][i] = -ll[k][i] - ll[k][i] / tl * d;
-                dua[k][i] = -lu[k][i] + lu[k][i] / tu * d;
-                if (d < 0.0 && -tl / d < aaff) aaff = -tl / d;
-                if (d > 0.0 && tu / d < aaff) aaff = tu / d;
+                const double tl = tlo[k][i], tu = tup[k][i];
+                const double d = ua[k][i];
+                const double el = d + rbl[k][i], eu = -d + rbu[k][i];      /* affine directions of the two slacks */
+                dla[k][i] = -ll[k][i] - ll[k][i] / tl * el;
+                dua[k][i] = -lu[k][i] - lu[k][i] / tu * eu;
+                if (el < 0.0 && -tl / el < aaff) aaff = -tl / el;
+                if (eu < 0.0 && -tu / eu < aaff) aaff = -tu / eu;
                 if (dla[k][i] < 0.0 && -ll[k][i] / dla[k][i] < aaff) aaff = -ll[k][i] / dla[k][i];
                 if (dua[k][i] < 0.0 && -lu[k][i] / dua[k][i] < aaff) aaff = -lu[k][i] / dua[k][i];
             }
         double muaff = 0.0;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
-                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                const double d = ua[k][i] - u[k][i];
-                muaff += (ll[k][i] + aaff * dla[k][i]) * (tl + aaff * d) +
-                         (lu[k][i] + aaff * dua[k][i]) * (tu - aaff * d);
+                const double tl = tlo[k][i], tu = tup[k][i];
+                const double d = ua[k][i];
+                const double el = d + rbl[k][i], eu = -d + rbu[k][i];
+                muaff += (ll[k][i] + aaff * dla[k][i]) * (tl + aaff * el) +
+                         (lu[k][i] + aaff * dua[k][i]) * (tu + aaff * eu);
             }
         muaff /= nc;
         double sg = muaff / mu;
@@ -862,9 +983,10 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         /* corrector: homogeneous solve for the change of the input gradient */
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
-                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                const double d = ua[k][i] - u[k][i];
-                const double cl = dla[k][i] * d, cu = dua[k][i] * (-d);
+                const double tl = tlo[k][i], tu = tup[k][i];
+                const double d = ua[k][i];
+                const double el = d + rbl[k][i], eu = -d + rbu[k][i];
+                const double cl = dla[k][i] * el, cu = dua[k][i] * eu;
                 rh[k][i] = -(sg * mu - cl) / tl + (sg * mu - cu) / tu;
             }
         riccati_backward(p, sig, rh, 1, 0, &f, NULL);
@@ -872,15 +994,18 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         double amax = 1e300;
         for (int k = 0; k < N; k++)
             for (int i = 0; i < p->nu[k]; i++) {
-                const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                const double da = ua[k][i] - u[k][i];
-                const double cl = dla[k][i] * da, cu = dua[k][i] * (-da);
+                const double tl = tlo[k][i], tu = tup[k][i];
+                const double da = ua[k][i];
+                const double el = da + rbl[k][i], eu = -da + rbu[k][i];
+                const double cl = dla[k][i] * el, cu = dua[k][i] * eu;
                 const double d = da + du[k][i];
                 du[k][i] = d;
-                dla[k][i] = -(ll[k][i] * tl + cl - sg * mu) / tl - ll[k][i] / tl * d;
-                dua[k][i] = -(lu[k][i] * tu + cu - sg * mu) / tu + lu[k][i] / tu * d;
-                if (d < 0.0 && -tl / d < amax) amax = -tl / d;
-                if (d > 0.0 && tu / d < amax) amax = tu / d;
+                dtl[k][i] = d + rbl[k][i];
+                dtu[k][i] = -d + rbu[k][i];
+                dla[k][i] = -(ll[k][i] * tl + cl - sg * mu) / tl - ll[k][i] / tl * dtl[k][i];
+                dua[k][i] = -(lu[k][i] * tu + cu - sg * mu) / tu - lu[k][i] / tu * dtu[k][i];
+                if (dtl[k][i] < 0.0 && -tl / dtl[k][i] < amax) amax = -tl / dtl[k][i];
+                if (dtu[k][i] < 0.0 && -tu / dtu[k][i] < amax) amax = -tu / dtu[k][i];
                 if (dla[k][i] < 0.0 && -ll[k][i] / dla[k][i] < amax) amax = -ll[k][i] / dla[k][i];
                 if (dua[k][i] < 0.0 && -lu[k][i] / dua[k][i] < amax) amax = -lu[k][i] / dua[k][i];
             }
@@ -895,9 +1020,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 double mun = 0.0, pmin = 1e300;
                 for (int k = 0; k < N; k++)
                     for (int i = 0; i < p->nu[k]; i++) {
-                        const double tl = u[k][i] - p->lo[k][i], tu = p->hi[k][i] - u[k][i];
-                        const double p1 = (ll[k][i] + alpha * dla[k][i]) * (tl + alpha * du[k][i]);
-                        const double p2 = (lu[k][i] + alpha * dua[k][i]) * (tu - alpha * du[k][i]);
+                        const double p1 = (ll[k][i] + alpha * dla[k][i]) * (tlo[k][i] + alpha * dtl[k][i]);
+                        const double p2 = (lu[k][i] + alpha * dua[k][i]) * (tup[k][i] + alpha * dtu[k][i]);
                         mun += p1 + p2;
                         if (p1 < pmin) pmin = p1;
                         if (p2 < pmin) pmin = p2;
@@ -914,6 +1038,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 const double sw = fabs(alpha * du[k][i]) / (p->hi[k][i] - p->lo[k][i]);
                 if (sw > step_last) step_last = sw;
                 u[k][i] += alpha * du[k][i];
+                tlo[k][i] += alpha * dtl[k][i];
+                tup[k][i] += alpha * dtu[k][i];
                 ll[k][i] += alpha * dla[k][i];
                 lu[k][i] += alpha * dua[k][i];
             }
@@ -921,44 +1047,11 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d mu %.3e aaff %.3e muaff %.3e sg %.3e alpha %.3e rho %.3e\n", it, mu, aaff, muaff, sg, alpha, rho);
     }
     /* final rollout of the states from the inputs (dynamics are affine) */
-    for (int i = 0; i < NX; i++) x[i] = dx0 ? dx0[i] : 0.0;
-    if (!polished) for (int k = 0; k < N; k++)
-        for (int i = 0; i < NX; i++) {
-            double s = p->b[k][i];
-            for (int j = 0; j < NX; j++) s += p->A[k][i * NX + j] * x[k * NX + j];
-            for (int j = 0; j < p->nu[k]; j++) s += p->B[k][i * p->nu[k] + j] * u[k][j];
-            x[(k + 1) * NX + i] = s;
-        }
+    if (!polished) ipm_rollout(p, dx0, u, x);
     if (st) {
         /* TRUE residuals, recomputed from scratch (diagnostics for the tests) */
-        double pi[NX], pin[NX], rs = 0.0, rc = 0.0;
-        for (int i = 0; i < NX; i++) {
-            double s = p->qN[i];
-            for (int j = 0; j < NX; j++) s += p->QN[i * NX + j] * x[N * NX + j];
-            pi[i] = s;
-        }
-        for (int k = N - 1; k >= 0; k--) {
-            const int m = p->nu[k];
-            for (int i = 0; i < m; i++) {
-                double s = p->r[k][i] - ll[k][i] + lu[k][i];
-                for (int j = 0; j < m; j++) s += p->R[k][i * m + j] * u[k][j];
-                for (int j = 0; j < NX; j++) s += p->S[k][i * NX + j] * x[k * NX + j];
-                for (int j = 0; j < NX; j++) s += p->B[k][j * m + i] * pi[j];
-                if (fabs(s) > rs) rs = fabs(s);
-                const double c1 = ll[k][i] * (u[k][i] - p->lo[k][i]);
-                const double c2 = lu[k][i] * (p->hi[k][i] - u[k][i]);
-                if (c1 > rc) rc = c1;
-                if (c2 > rc) rc = c2;
-            }
-            for (int i = 0; i < NX; i++) {
-                double s = p->q[k][i];
-                for (int j = 0; j < NX; j++) s += p->Q[k][i * NX + j] * x[k * NX + j];
-                for (int j = 0; j < m; j++) s += p->S[k][j * NX + i] * u[k][j];
-                for (int j = 0; j < NX; j++) s += p->A[k][j * NX + i] * pi[j];
-                pin[i] = s;
-            }
-            memcpy(pi, pin, sizeof(pi));
-        }
+        double rs = 0.0, rc = 0.0, rb = 0.0;
+        ipm_true_residuals(p, dx0, u, ll, lu, polished ? NULL : tlo, polished ? NULL : tup, polished ? x : NULL, &rs, &rc, &rb);
         st->qp_iter = it; st->qp_status = status; st->res_stat = rs; st->res_eq = 0.0;
         st->res_comp = rc; st->mu = mu; st->rho = rho; st->polished = polished; st->polish_attempts = npolish;
         st->growth = growth; st->step_last = step_last; st->untrusted = untrusted;
@@ -966,9 +1059,11 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     for (int k = 0; k < N; k++) {
         orc_free(f.L[k]); orc_free(f.M[k]); orc_free(f.m[k]); orc_free(ll[k]); orc_free(lu[k]); orc_free(sig[k]);
         orc_free(rh[k]); orc_free(ua[k]); orc_free(du[k]); orc_free(dla[k]); orc_free(dua[k]);
+        orc_free(tlo[k]); orc_free(tup[k]); orc_free(dtl[k]); orc_free(dtu[k]); orc_free(rbl[k]); orc_free(rbu[k]); orc_free(bsh[k]); orc_free(qsh[k]);
     }
     orc_free(f.L); orc_free(f.M); orc_free(f.m); orc_free(ll); orc_free(lu); orc_free(sig); orc_free(rh); orc_free(ua);
-    orc_free(du); orc_free(dla); orc_free(dua); orc_free(xh);
+    orc_free(du); orc_free(dla); orc_free(dua); orc_free(tlo); orc_free(tup); orc_free(dtl); orc_free(dtu); orc_free(rbl); orc_free(rbu);
+    orc_free(xh); orc_free(bsh); orc_free(qsh);
     return status;
 }
 

@@ -74,6 +74,11 @@ typedef struct orc_config {
                                acados SQP_RTI), 2 = reported (some versions; the caller then discards the command,
                                controller.py:448-450) */
     int qp_warm_start;      /* 1: an attempt that runs out of passes hands its last pass to the interior point as the start point */
+    int qp_exit_mode;       /* 0 (default): exit on the tracked measures - mean complementarity mu <= qp_tol_comp, stationarity factor
+                               rho <= qp_tol_stat, last step <= qp_tol_step.  1: [UPSTREAM U9] HPIPM's own exit test - the TRUE
+                               residuals of the iterate in the infinity norm, stationarity and bound equations <= qp_tol_stat, max
+                               complementarity product <= qp_tol_comp (HPIPM / acados default 1e-8 each; controller.py:179-190 sets
+                               none).  Mode 1 exists to predict acados' accuracy floor on this OCP (tests/test_acados_floor.py)   */
 } orc_config;
 
 typedef struct orc_stats {
