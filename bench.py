@@ -226,8 +226,6 @@ def secondary_rows(args, B, N, local, dev, tdt, npdt, torch, _lib, NmpcOcpSolver
     for name, over, x0, what in variants:
         cfg = _lib.default_config(N=N, max_batch=B, device=local,
                                   dtype=dict(f64=_lib.DTYPE_F64, f32=_lib.DTYPE_F32, f32io=_lib.DTYPE_F32IO)[args.dtype])
-        if args.dtype == "f32":
-            cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
         cfg.update(**over)
         sv = NmpcOcpSolver(cfg)
         sv.set_timing(False)
@@ -314,7 +312,8 @@ def main() -> None:
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
     ap.add_argument("--dtype", choices=["f64", "f32", "f32io"], default="f64",
-                    help="f32io: FP32 device buffers, FP64 arithmetic (NMPC_DTYPE_F32IO)")
+                    help="f32io (= f32 since round 5): FP32 device buffers, FP64 arithmetic (NMPC_DTYPE_F32IO); the JSON line's dtype "
+                         "stays f64 - the arithmetic - with config.device_buffers = f32")
     ap.add_argument("--dist", choices=["near_hover", "aggressive"], default="near_hover")
     ap.add_argument("--yref", choices=["per_instance", "broadcast"], default="per_instance")
     ap.add_argument("--no-share", action="store_true", help="do not exploit the shared cold-start linearisation")
@@ -335,6 +334,8 @@ def main() -> None:
     ap.add_argument("--polish-budget", type=int, default=None, help="override nmpc_config.qp_polish_budget (passes in total)")
     ap.add_argument("--cpu-sample", type=int, default=4096)
     args = ap.parse_args()
+    if args.dtype == "f32":
+        args.dtype = "f32io"      # BASELINE config 3 ("FP32"): served by FP32 buffers on the FP64 kernels
 
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")    # multi-process GPU work on this pool needs dmabuf IPC (already exported on the boxes)
     world_env = int(os.environ.get("WORLD_SIZE", "1"))
@@ -384,8 +385,6 @@ def main() -> None:
                               dtype=lib_dtype,
                               flags=(0 if args.no_share else _lib.FLAG_SHARE_COLD_START)
                               | (_lib.FLAG_TEAM_MAPPING if args.mapping == "team" else 0))
-    if args.dtype == "f32":
-        cfg.update(qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
     if args.polish_ckpt is not None:
         cfg.update(qp_polish_ckpt=args.polish_ckpt)
     if args.polish_passes is not None:
@@ -629,7 +628,7 @@ def main() -> None:
         alg_b = algorithmic_bytes(N, esz, bcast, args.traj_out)
         n_kkt = n_ipm + st["polish_mean"]
         flops = algorithmic_flops(N, n_kkt)
-        f_peak = FP32_VEC_PEAK_TF if args.dtype == "f32" else FP64_VEC_PEAK_TF
+        f_peak = FP64_VEC_PEAK_TF
         hbm_alg_gbs = alg_b * B / kern_s / 1e9
         alu_tf = flops * B / kern_s / 1e12
         flops_x = executed_flops(N, n_ipm, st["polish_mean"], not args.no_share)
@@ -641,8 +640,7 @@ def main() -> None:
         sched = solver.last_schedule()
         split = sched["split"]                         # default FP64 path: first attempt by k_team_as
         inplace = sched["inplace"]                     # ... which also continues the attempts that fail (no work-list launch)
-        new_qp = args.dtype in ("f64", "f32io") and os.environ.get("NMPC_TEAM_QP", "1") != "0" and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
-        kname = ("k_team_as" if split else ("k_team_qp" if new_qp else "k_team_ipm")) if args.mapping == "team" else "k_ipm"
+        kname = ("k_team_as" if split else "k_team_qp") if args.mapping == "team" else "k_ipm"
         pmc_file = ROOT / "profiles" / f"latest_{args.mapping}_b{B}_{args.dtype}_pmc_summary.json"
         if pmc_file.exists() and not args.no_share and not bcast and not args.traj_out and N == 20:
             pmc_all = json.loads(pmc_file.read_text())
@@ -656,7 +654,7 @@ def main() -> None:
                 traffic_note = f"stale profile: {pmc_file.name} was captured on kernel sources {pmc_all.get('source_hash')}, this build is {source_hash()}"
             elif "FETCH_SIZE" in pmc and "WRITE_SIZE" in pmc:
                 traffic = (2.0 * pmc["FETCH_SIZE"]["mean"] + pmc["WRITE_SIZE"]["mean"]) * 1024.0
-                tail = pmc_all.get("k_team_qp_list", pmc_all.get("k_team_ipm_list", {}))
+                tail = pmc_all.get("k_team_qp_list", {})
                 if split and not inplace and "FETCH_SIZE" in tail and "WRITE_SIZE" in tail:      # both launches of a step
                     traffic += (2.0 * tail["FETCH_SIZE"]["mean"] + tail["WRITE_SIZE"]["mean"]) * 1024.0
         kernel_name = (("k_team_as" if inplace else "k_team_as + k_team_qp_list") if split else kname) if args.mapping == "team" else "k_ipm"
@@ -674,7 +672,7 @@ def main() -> None:
         # FP64 matrix peak of gfx950 equals the vector peak, 78.6 TFLOP/s), so that is the roof quoted for it;
         # every other variant is a vector-ALU kernel and keeps the HBM line of the contract, with the flop
         # figures beside it.  Both sub-objects are always present.
-        mfma_path = args.mapping == "team" and args.dtype in ("f64", "f32io") and not args.condensed and os.environ.get("NMPC_TEAM_MFMA", "1") != "0"
+        mfma_path = args.mapping == "team" and not args.condensed
         common = dict(kernel=kernel_name, traffic=traffic, traffic_source=(pmc_file.name if traffic is not None else traffic_note),
                       kernel_ms=kern_s * 1e3, kernel_ms_isolated=st["ms_solve"] + (0.0 if (split and inplace) else st.get("ms_tail", 0.0)), prepare_ms=st["ms_prepare"],
                       launches=(dict(k_team_as_ms_isolated=st["ms_solve"], k_team_qp_list_ms_isolated=(None if inplace else st["ms_tail"]),

@@ -44,7 +44,9 @@ extern "C" {
 #define NMPC_EHIP (-2)
 
 #define NMPC_DTYPE_F64 0   /* device buffers and arithmetic double */
-#define NMPC_DTYPE_F32 1   /* device buffers and arithmetic float (row-form vector kernels; ~1e-5 N on u0) */
+#define NMPC_DTYPE_F32 1   /* since round 5 the same as NMPC_DTYPE_F32IO.  (Rounds 1-4: FP32 arithmetic on a kernel of its own, 5e-5 .. 5e-3 N
+                              from the FP64 answer - narrower than the reference's own arithmetic (acados / HPIPM are double,
+                              SURVEY 8) and outside the 1e-6 the path is held to: retired.)                                   */
 #define NMPC_DTYPE_F32IO 2 /* device buffers float, arithmetic and workspace DOUBLE: the FP64 tile kernels read and write the
                               caller's float arrays directly (half the compulsory bytes of F64, u0 exact to float rounding of
                               the inputs).  Needs the default path: team mapping, qp_polish on, no condensing               */
@@ -85,7 +87,7 @@ typedef struct nmpc_config {
     double qp_tau;             /* fraction to the boundary */
     double qp_thr0;            /* initial distance from the bounds, absolute ... */
     double qp_thr0_rel;        /* ... and relative to the box width (the larger applies) */
-    int32_t dtype;             /* NMPC_DTYPE_F64 | NMPC_DTYPE_F32 | NMPC_DTYPE_F32IO */
+    int32_t dtype;             /* NMPC_DTYPE_F64 | NMPC_DTYPE_F32IO (NMPC_DTYPE_F32 is accepted as the latter) */
     int32_t device;            /* HIP device ordinal */
     int32_t max_batch;         /* workspace is sized for this many instances */
     uint32_t flags;            /* NMPC_FLAG_* */
@@ -132,8 +134,8 @@ typedef struct nmpc_stats {
     double polish_mean;        /* active-set passes per instance (team mapping), mean / max */
     int32_t polish_max;
     int32_t n_polished;        /* instances that finished with an accepted active-set solution */
-    int32_t n_tail;            /* instances the active-set kernel handed to the general kernel (default FP64 path) */
-    double ms_tail;            /* device time of that second launch (k_team_ipm_list); ms_solve is then the first launch alone */
+    int32_t n_tail;            /* instances whose first active-set attempt failed (continued on the interior point; default path) */
+    double ms_tail;            /* device time of the launches after k_team_as (k_team_qp_list / the block-parallel tail), 0 when k_team_as continued them itself */
 } nmpc_stats;
 
 typedef struct nmpc_solver nmpc_solver; /* opaque; owns all device memory */

@@ -189,7 +189,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     // operands of a stage - its 11 stored tiles and 8 to 11 scalars - arrive TWO stages ahead in two alternating register sets: a block
     // sweep runs on a few waves (the tail's lists are short), its stage is shorter than an HBM round trip, and one stage ahead left part of
     // every load exposed (2.5 us per stage against 1.45 us for the same stage in the solver's sweep, whose tiles sit in LDS)
-    struct StOps { T pfs[12], yx, yu, xl, ul, pc, pca, ulc, u, ll, lu; };
+    struct StOps { T pfs[12], yx, yu, xl, ul, pc, pca, ulc, u, ll, lu, tl, tu, uc; };
     auto fetch_ops = [&](int kq, StOps &o) {
         const int kc = kq > s ? kq : s;                     // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
         const int k = shared ? 0 : kc;
@@ -198,8 +198,11 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
         o.yx = (T)yr[(size_t)kc * NY + rr]; o.yu = (T)yr[(size_t)kc * NY + NX + ta];
         o.xl = xlin(kc); o.ul = ulin(kc, ta);
         o.pc = tIV[kc * IV_ROWS + 16 + j]; o.pca = tIV[kc * IV_ROWS + 16 + ta]; o.ulc = ulin(kc, j);
-        o.u = 0; o.ll = 0; o.lu = 0;                        // the iterate of input a (interior-point iteration)
-        if (TAIL) { const T *ivn = tIV + kc * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; }
+        o.u = 0; o.ll = 0; o.lu = 0; o.tl = 1; o.tu = 1; o.uc = 0;      // the iterate of input a, the input of component c (interior-point iteration)
+        if (TAIL) {
+            const T *ivn = tIV + kc * IV_ROWS;
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.uc = ivn[j];
+        }
     };
 
     T Pt[4][4];
@@ -249,6 +252,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
         NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = o.pfs[kt * 3]; Aq1b[kt] = o.pfs[kt * 3 + 1]; Bt[kt] = o.pfs[kt * 3 + 2]; }
         StageIn sin;
         sin.ul = o.ul; sin.pc = o.pc; sin.pca = o.pca; sin.ulc = o.ulc; sin.u_it = o.u; sin.ll_it = o.ll; sin.lu_it = o.lu;
+        sin.tl_it = o.tl; sin.tu_it = o.tu; sin.u_itc = o.uc;
         T rk = Wr_a * (sin.ul - o.yu);
         sin.q_r = Wq_r * (o.xl - o.yx);
         asm volatile("" : "+v"(rk));

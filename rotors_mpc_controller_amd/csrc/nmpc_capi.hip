@@ -1,9 +1,10 @@
 // nmpc_capi.hip -- HIP kernels (gfx950) and the C ABI of include/rotors_nmpc.h.
 //
-// Kernels: k_team_ipm (16 lanes per MPC instance, 4 instances per wave; preparation fused in; FP64 Riccati
-// sweeps on v_mfma_f64_4x4x4 register tiles; the default), k_team_prepare (the same preparation as a
-// separate launch), k_prepare / k_ipm (one instance per lane), k_cond_ipm (partial-condensing fidelity
-// path) and the element-wise kernels of nmpc_aux.hpp.  Every workgroup is one 64-lane wave, so a batch becomes
+// Kernels defined here: k_prepare / k_ipm (one instance per lane: the mapping BASELINE.json's north_star names, kept as the
+// fidelity path of the lane layout), k_cond_ipm (partial condensing as acados configures HPIPM, fidelity path) and the
+// element-wise kernels of nmpc_aux.hpp.  The kernels that run by default - k_team_as, k_team_qp, k_team_qp_list, k_team_tail
+// (16 lanes per MPC instance, 4 instances per wave, FP64 Riccati sweeps on v_mfma_f64_4x4x4 register tiles) and the block
+// sweeps - live in nmpc_as.hip / nmpc_qp(f).hip / nmpc_block(f).hip.  Every workgroup is one 64-lane wave, so a batch becomes
 // hundreds to thousands of independent workgroups that the dispatcher spreads over all XCDs; no
 // inter-workgroup communication exists on this path (instances are independent), so no
 // release/acquire protocol is needed.
@@ -55,55 +56,6 @@ __global__ __launch_bounds__(64) void k_cond_ipm(Consts<T> c, Work<T> w, CondWor
     if (lane < B) lane_cond_ipm(c, w, cw, out, lane);
 }
 
-// preparation phase, team mapping
-template <class T>
-__global__ __launch_bounds__(64) void k_team_prepare(Consts<T> c, Work<T> w, Inputs<T> in, int B)
-{
-    team_prepare(c, w, in, B, 4);
-}
-
-// QP phase, team mapping: 4 instances per 64-lane wave, one wave per workgroup
-// W = waves per SIMD the register allocation must allow (512 / 256 / 128 VGPRs per lane)
-// fused != 0: the wave first prepares its own instances (same instance <-> team assignment), which saves
-// a launch and lets the solve start while other waves still linearise
-// MF: tile form of the factor sweep on v_mfma_f64_4x4x4 (FP64 only)
-template <class T, int W, bool SHARED, bool MF>
-__global__ __launch_bounds__(64, W) void k_team_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, TeamWork<T> tw, int B, int fused, int tpw)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    const long long t_entry = NMPC_PROF_NOW();
-    if (fused) {
-        team_prepare(c, w, in, B, tpw, reinterpret_cast<T *>(smem_raw));
-        __syncthreads();           // workgroup-scope visibility of the staged rows (one wave per workgroup)
-    }
-    team_ipm<T, W == 1, SHARED, MF>(c, w, out, tw, B, tpw, reinterpret_cast<T *>(smem_raw), t_entry, SHARED && fused != 0);
-}
-
-// default FP64 path, second launch: the general kernel (interior point iteration + later active-set attempts) on
-// the instances the first launch appended to the work list - usually none.  A fixed small grid strides over the
-// list; the last workgroup to finish resets the list for the next solve.
-template <bool SHARED, class TI>
-__global__ __launch_bounds__(64, 1) void k_team_ipm_list(Consts<double> c, Work<double> w, Inputs<TI> in, Outputs<TI> out,
-                                                         TeamWork<double> tw, WorkList wl, int B)
-{
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
-    double *smem = reinterpret_cast<double *>(smem_raw);
-    const int n = *wl.count;
-    const int team = (threadIdx.x >> 2) & 3;
-    for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
-        const int e = base + team;
-        const int inst = e < n ? wl.list[e] : -1;
-        team_prepare<double, TI>(c, w, in, B, 4, smem, inst);
-        __syncthreads();
-        team_ipm<double, true, SHARED, true, TI>(c, w, out, tw, B, 4, smem, 0ll, SHARED, inst, true);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(wl.done, 1);          // every workgroup has read the count before it arrives here
-        if (t == (int)gridDim.x - 1) { *wl.count = 0; *wl.done = 0; }
-    }
-}
-
 }  // namespace
 
 struct nmpc_solver {
@@ -129,7 +81,6 @@ struct nmpc_solver {
     int lds_overlap = 1;             // NMPC_LDS_OVERLAP=0: the per-stage variant's stage cache behind the evaluation-point buffer (round 3)
     int qp_noflag = 0;               // NMPC_QP_NOFLAG=1: k_team_qp from nmpc_qp.hip (default code generation) instead of nmpc_qpf.hip
     int as_v256 = 0;                 // NMPC_AS_BUILD=v256: the 256-register build with the LDS stage cache (nmpc_qp.hip, OCC = 3)
-    int team_qp = 1;                 // general FP64 kernel = k_team_qp / k_team_qp_list (nmpc_team_as.hpp); NMPC_TEAM_QP=0: round-1 kernel k_team_ipm
     int team_lstg = -1;              // NMPC_TEAM_LSTG caps the stages whose factors stay in LDS (experiments; -1 = what fits)
     long long *d_prof = nullptr;   // only allocated in NMPC_PROFILE builds
     // device staging for the host-pointer entry points
@@ -170,8 +121,6 @@ struct nmpc_solver {
     int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
-    int team_fused = 1; // preparation fused into k_team_ipm; NMPC_TEAM_FUSED=0 launches it separately
-    int team_mfma = 1;  // FP64 factor sweep in tile form on v_mfma_f64_4x4x4; NMPC_TEAM_MFMA=0 keeps the VALU form
 
     // canaries around every device allocation of the handle (NMPC_GUARD=<KiB>, off by default): nmpc_debug_guard_check
     size_t guard = 0;
@@ -304,12 +253,17 @@ static int alloc_ws(nmpc_solver *s)
 {
     const size_t N = (size_t)s->cfg.N, Bp = (size_t)s->Bp, e = s->wsz;
     const size_t Bw = Bp + 1;      // per-instance team workspaces carry one spare row: idle teams of a wave work there
+    // lane layout ([row][Bp]: k_prepare / k_ipm / k_cond_ipm) and team layout ([inst][rows]) need different arrays; a handle runs one of them
+    const bool team = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
+    const size_t ln = team ? 0 : 1;
     struct { void **p; size_t n; } a[] = {
-        {&s->AB, N * AB_ROWS * Bp * e}, {&s->bv, N * NX * Bp * e}, {&s->qr, (N * QR_ROWS + NX) * Bp * e},
-        {&s->xl, (N + 1) * NX * Bp * e}, {&s->ul, N * NU * Bp * e}, {&s->LM, N * TLM_ROWS * Bw * e},
+        {&s->AB, std::max<size_t>(1, ln * N * AB_ROWS * Bp) * e}, {&s->bv, std::max<size_t>(1, ln * N * NX * Bp) * e},
+        {&s->qr, std::max<size_t>(1, ln * (N * QR_ROWS + NX) * Bp) * e},
+        {&s->xl, std::max<size_t>(1, ln * (N + 1) * NX * Bp) * e}, {&s->ul, std::max<size_t>(1, ln * N * NU * Bp) * e},
+        {&s->LM, N * (team ? (size_t)TLM_ROWS : (size_t)LM_ROWS) * Bw * e},
         {&s->iv, N * IV_ROWS * Bw * e},
-        {&s->tAB, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? N * TAB_ROWS * Bw : 1) * e},
-        {&s->tP, ((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bw : 1) * e},
+        {&s->tAB, (team ? N * TAB_ROWS * Bw : 1) * e},
+        {&s->tP, (team && s->cfg.qp_polish ? (size_t)(ckpt_stages(s->cfg) + 1) * TP_ROWS * Bw : 1) * e},
         {(void **)&s->d_iters, Bp * sizeof(int32_t)},
         {(void **)&s->d_status, Bp * sizeof(int32_t)}, {(void **)&s->d_npol, Bp * sizeof(int32_t)},
         {(void **)&s->d_wl, (Bp + 2) * sizeof(int)}, {(void **)&s->d_gbase, (Bp + 1) * sizeof(double)}};
@@ -344,13 +298,16 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         return bad("nmpc_create: only sim_method_num_stages = 2 (explicit midpoint, controller.py:187) is built");
     if (cfg->sim_num_steps < 1) return bad("nmpc_create: sim_num_steps must be >= 1");
     if (cfg->dtype != NMPC_DTYPE_F64 && cfg->dtype != NMPC_DTYPE_F32 && cfg->dtype != NMPC_DTYPE_F32IO) return bad("nmpc_create: bad dtype");
-    if (cfg->dtype == NMPC_DTYPE_F32IO) {
+    // FP32 buffers (NMPC_DTYPE_F32 = NMPC_DTYPE_F32IO since round 5: the arithmetic is FP64 either way, include/rotors_nmpc.h)
+    if (cfg->dtype != NMPC_DTYPE_F64) {
         const bool ok = (cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP) && cfg->qp_polish &&
                         cfg->qp_polish_mu >= cfg->qp_mu0 &&
                         cfg->sim_num_steps <= AS_MAX_STEPS && !(cfg->qp_mu0 <= cfg->qp_tol_comp);
-        if (!ok) return bad("nmpc_create: NMPC_DTYPE_F32IO runs on the default path only (team mapping, qp_polish = 1 with its first "
-                            "attempt before any interior-point iteration, sim_num_steps <= 4, no condensing)");
+        if (!ok) return bad("nmpc_create: FP32 buffers (NMPC_DTYPE_F32 / NMPC_DTYPE_F32IO) run on the default path only (team mapping, "
+                            "qp_polish = 1 with its first attempt before any interior-point iteration, sim_num_steps <= 4, no condensing)");
     }
+    if ((cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP) && cfg->sim_num_steps > AS_MAX_STEPS)
+        return bad("nmpc_create: the team mapping is built for sim_num_steps <= 4 (controller.py:188 sets 2); clear NMPC_FLAG_TEAM_MAPPING for more");
     if (cfg->max_batch < 1) return bad("nmpc_create: max_batch must be >= 1");
     if (!(cfg->mass > 0) || !(cfg->inertia[0] > 0) || !(cfg->inertia[1] > 0) || !(cfg->inertia[2] > 0))
         return bad("nmpc_create: mass and inertia must be positive");
@@ -382,24 +339,15 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     // changed nothing or lost: N = 600 12 / 24 42.8 ms).  The near-hover N = 20 set needs 3 passes at most either way.
     if (s->cfg.qp_polish_passes <= 0) s->cfg.qp_polish_passes = 8;
     if (s->cfg.qp_polish_budget <= 0) s->cfg.qp_polish_budget = 16;
-    if (cfg->dtype == NMPC_DTYPE_F32) {
-        // FP32 cannot resolve the FP64 stopping thresholds; floors found by sweeping the
-        // tolerance against the FP64 oracle (max |u0| error 2.4e-4 .. 7.9e-4 N at these values)
-        s->cfg.qp_tol_comp = std::max(cfg->qp_tol_comp, 1e-8);
-        s->cfg.qp_tol_stat = std::max(cfg->qp_tol_stat, 1e-6);
-        s->cfg.qp_iter_max = std::min(cfg->qp_iter_max, 30);
-    }
+    if (cfg->dtype == NMPC_DTYPE_F32) s->cfg.dtype = NMPC_DTYPE_F32IO;     // one FP32-buffer path
     s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
-    s->wsz = cfg->dtype == NMPC_DTYPE_F32 ? 4 : 8;
+    s->wsz = 8;                                                             // workspace and arithmetic are always double
     if (const char *e = std::getenv("NMPC_TEAM_OCC")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2) s->team_occ = v;
     }
     if (const char *e = std::getenv("NMPC_GUARD")) s->guard = (size_t)std::max(0, std::atoi(e)) * 1024;
-    if (const char *e = std::getenv("NMPC_TEAM_FUSED")) s->team_fused = std::atoi(e) != 0;
-    if (const char *e = std::getenv("NMPC_TEAM_MFMA")) s->team_mfma = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
-    if (const char *e = std::getenv("NMPC_TEAM_QP")) s->team_qp = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_INPLACE")) s->team_inplace = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LIST_GRID")) s->list_grid = std::max(1, std::min(4096, std::atoi(e)));
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
@@ -432,9 +380,9 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         // more attempt) with every factorisation cut into blocks.  Needs the FP64 tile kernels, the warm start, and an attempt
         // schedule in which the second attempt is the last (the tail never leaves a second warm start behind).
         const nmpc_config &g = s->cfg;
-        const bool can = g.dtype != NMPC_DTYPE_F32 && (g.flags & NMPC_FLAG_TEAM_MAPPING) && !(g.flags & NMPC_FLAG_CONDENSED_QP) && g.qp_polish &&
+        const bool can = (g.flags & NMPC_FLAG_TEAM_MAPPING) && !(g.flags & NMPC_FLAG_CONDENSED_QP) && g.qp_polish &&
                          g.qp_warm_start && g.qp_polish_budget > g.qp_polish_passes && g.qp_polish_budget <= 2 * g.qp_polish_passes &&
-                         g.sim_num_steps <= AS_MAX_STEPS && s->team_qp && s->team_split && s->team_mfma && g.N >= 8;
+                         g.sim_num_steps <= AS_MAX_STEPS && s->team_split && g.N >= 8;
         const bool want = s->block_tail < 0 ? g.N >= 160 : s->block_tail != 0;
         if (can && want) {
             int J = s->block_J > 0 ? s->block_J : (int)std::lround(0.7 * std::sqrt((double)g.N));
@@ -589,12 +537,11 @@ template <class TI>
 static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<double> &w, const Inputs<TI> &in, const Outputs<TI> &out,
                         const TeamWork<double> &tw, int B, int tpw, hipStream_t st)
 {
-    const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);
+    const dim3 tgrid((B + tpw - 1) / tpw);
     WorkList wl;
     wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
     const int nlist = std::min((B + 3) / 4, s->list_grid);      // usually empty: keep the launch small (each workgroup strides over the list)
     const bool traj = out.x_out != nullptr || out.u_out != nullptr;
-    const size_t lds = (size_t)4 * TEAM_LDS * sizeof(double);
     int occ_as = s->team_occ;
     // Two waves per SIMD (256 registers, no LDS stage cache) pay only where one wave per SIMD would leave a small second round: just
     // above 1024 waves.  Re-measured on the round-4 builds (profiles/r04v_occupancy_sweep.txt; two-wave / one-wave build, M solves/s):
@@ -617,9 +564,9 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
     al.lds_stride = lds_stride; al.lstg = lstg; al.lm_off = base_as; al.occ = occ_as; al.shared = c.shared != 0; al.traj = traj;
     al.lds_bytes = lds_as; al.stream = st;
-    const bool tail = s->team_qp && s->tail_J > 0;
+    const bool tail = s->tail_J > 0;
     // failed first attempts continue inside k_team_as (team_as_kernel): the one-wave builds, the team_as kernels, short horizons
-    const bool inplace = s->team_inplace && s->team_qp && !tail && occ_as == 1 && !s->as_v256 && as_cont_built(c.shared != 0, traj);
+    const bool inplace = s->team_inplace && !tail && occ_as == 1 && !s->as_v256 && as_cont_built(c.shared != 0, traj);
     if (inplace) {
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);               // the MODE 2 carve: IP_LM_ROWS per cached stage, same base
@@ -705,14 +652,11 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         HIP_TRY(s, (hipError_t)launch_team_qp(rl, in, out));
     } else if (inplace) {
         // nothing was handed over: every instance finished inside k_team_as
-    } else if (s->team_qp) {
+    } else {
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1;
         HIP_TRY(s, (hipError_t)launch_qp_kind(s, ql, in, out));
-    } else {
-        if (c.shared) hipLaunchKernelGGL((k_team_ipm_list<true, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
-        else hipLaunchKernelGGL((k_team_ipm_list<false, TI>), dim3(nlist), tblock, lds, st, c, w, in, out, tw, wl, B);
     }
     HIP_TRY(s, hipGetLastError());
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[3], st));
@@ -750,10 +694,12 @@ static int launch_f32io(nmpc_solver *s, int B, const void *x0, const void *yref,
     return launch_split<float>(s, c, w, in, out, tw, B, tpw, st);
 }
 
-template <class T>
-static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
-                  const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
+// NMPC_DTYPE_F64: the default path (launch_split), the one-launch interior-point kernel k_team_qp for every other team-mapped
+// configuration, and the two fidelity paths of the lane layout (k_prepare + k_ipm | k_cond_ipm)
+static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
+                      const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
 {
+    using T = double;
     Consts<T> c;
     fill_consts(s->cfg, c);
     const bool cold = (x_init == nullptr || u_init == nullptr);
@@ -765,7 +711,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     w.prof = s->d_prof;
     w.npol = s->d_npol;
     w.tAB = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? (T *)s->tAB : nullptr;
-    w.gbase = (T *)s->d_gbase;        // (read by the FP64 tile kernels only)
+    w.gbase = (T *)s->d_gbase;
     Inputs<T> in;
     in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
     in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
@@ -774,30 +720,9 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out; out.status = status;
     const dim3 grid((B + 63) / 64), block(64);
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
-    // the team kernels keep the stage vectors as [inst][rows], the lane kernels as [row][Bp]: a team-mapped
-    // QP phase is always paired with the team-mapped preparation
-    const bool team_only = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
-    if (!((s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP)))
-        HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // only k_team_ipm writes it
-    // fused: preparation inside k_team_ipm (NMPC_TEAM_FUSED=0 keeps the two-kernel form, e.g. for profiling)
-    const bool team_qp = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
-    const int fused = (team_qp && s->team_fused) ? 1 : 0;
-    if (fused)
-        ;
-    else if (team_only)
-        hipLaunchKernelGGL(k_team_prepare<T>, dim3((B + 3) / 4), block, 0, st, c, w, in, B);
-    else
-        hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
-    HIP_TRY(s, hipGetLastError());
-    if (s->timing && !fused) HIP_TRY(s, hipEventRecord(s->ev[1], st));
-    if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
-        CondWork<T> cw;
-        const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
-        cond_layout(cw, s->cfg.N, N2);
-        cw.base = (T *)s->cond;
-        cw.Bp = s->Bp;
-        hipLaunchKernelGGL(k_cond_ipm<T>, grid, block, 0, st, c, w, cw, out, B);
-    } else if (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) {
+    const bool team = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
+    if (team) {
+        // the team kernels linearise inside the solve kernel and keep the stage data as [inst][rows]
         TeamWork<T> tw;
         tw.tLM = (T *)s->LM;
         tw.tIV = (T *)s->iv;
@@ -806,54 +731,39 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
         // put two waves on every SIMD, so that LDS/memory latency still has something to hide behind
         int tpw = s->team_tpw;
         if (tpw == 0) tpw = (B >= 2048) ? 4 : (B >= 512 ? 2 : 1);   // measured: 4 is best from B = 4096 up
-        const dim3 tgrid((B + tpw - 1) / tpw), tblock(64);   // always a full wave: idle teams shadow
-        int occ = s->team_occ;
-        // register budget: FP64 needs the whole 512-register file (the 256-register build spills);
-        // FP32 fits 256 and gains from two waves per SIMD once the batch supplies them (measured at
-        // B = 65536: 13.9 M vs 8.3 M solves/s)
-        if (occ == 0) occ = (sizeof(T) == 4 && B >= 16384) ? 2 : 1;
-        const size_t lds = (size_t)4 * TEAM_LDS * sizeof(T);
-        constexpr bool F64 = sizeof(T) == 8;
-        const bool mf = F64 && s->team_mfma;
-        // Default FP64 path: the active-set kernel makes the first attempt of every instance; the general kernel
-        // runs on the work list of what that attempt could not settle.  Taken when the single-kernel path would
-        // start with an active-set attempt as well (polish on, first attempt before any interior-point iteration).
-        const bool split = mf && fused && s->team_split && s->cfg.qp_polish && s->cfg.qp_polish_budget > 0 &&
-                           s->cfg.qp_polish_passes > 0 && s->cfg.qp_polish_mu >= s->cfg.qp_mu0 &&
-                           s->cfg.sim_num_steps <= AS_MAX_STEPS && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
-        if constexpr (F64) {
-            if (split) return launch_split<double>(s, c, w, in, out, tw, B, tpw, st);
-            // every other FP64 tile-form solve - qp_polish = 0, an attempt schedule that starts with interior-point iterations,
-            // NMPC_TEAM_SPLIT=0 - is ONE launch of k_team_qp (the same sweeps as the split path, nmpc_team_as.hpp)
-            if (mf && fused && s->team_qp && s->cfg.sim_num_steps <= AS_MAX_STEPS) {
-                WorkList wl;
-                wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
-                AsLaunch al;
-                al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
-                al.occ = 1; al.shared = c.shared != 0; al.traj = out.x_out != nullptr || out.u_out != nullptr;
-                al.stream = st; al.kind = 1;
-                qp_lds(s, c.shared != 0, al);
-                // the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator steps, as k_team_as - else the default one
-                HIP_TRY(s, (hipError_t)launch_qp_kind(s, al, in, out));
-                if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
-                s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
-                s->last_shared = c.shared != 0;
-                return 0;
-            }
-        }
-#define NMPC_LAUNCH_TEAM(W_, SH_, MF_) hipLaunchKernelGGL((k_team_ipm<T, W_, SH_, MF_>), tgrid, tblock, lds, st, c, w, in, out, tw, B, fused, tpw)
-        if (mf) {
-            if (occ == 1 && c.shared) NMPC_LAUNCH_TEAM(1, true, F64);
-            else if (occ == 1) NMPC_LAUNCH_TEAM(1, false, F64);
-            else if (c.shared) NMPC_LAUNCH_TEAM(2, true, F64);
-            else NMPC_LAUNCH_TEAM(2, false, F64);
-        } else {
-            if (occ == 1 && c.shared) NMPC_LAUNCH_TEAM(1, true, false);
-            else if (occ == 1) NMPC_LAUNCH_TEAM(1, false, false);
-            else if (c.shared) NMPC_LAUNCH_TEAM(2, true, false);
-            else NMPC_LAUNCH_TEAM(2, false, false);
-        }
-#undef NMPC_LAUNCH_TEAM
+        // Default path: the active-set kernel makes the first attempt of every instance and continues what that attempt cannot
+        // settle.  Taken when the QP starts with an active-set attempt (polish on, first attempt before any interior-point iteration).
+        const bool split = s->team_split && s->cfg.qp_polish && s->cfg.qp_polish_budget > 0 &&
+                           s->cfg.qp_polish_passes > 0 && s->cfg.qp_polish_mu >= s->cfg.qp_mu0 && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
+        if (split) return launch_split<double>(s, c, w, in, out, tw, B, tpw, st);
+        // every other tile-form solve - qp_polish = 0, an attempt schedule that starts with interior-point iterations,
+        // NMPC_TEAM_SPLIT=0 - is ONE launch of k_team_qp (the same sweeps as the split path, nmpc_team_as.hpp)
+        WorkList wl;
+        wl.count = s->d_wl; wl.done = s->d_wl + 1; wl.list = s->d_wl + 2;
+        AsLaunch al;
+        al.cp = (const Consts<double> *)s->d_consts; al.w = w; al.tw = tw; al.wl = wl; al.B = B; al.tpw = tpw;
+        al.occ = 1; al.shared = c.shared != 0; al.traj = out.x_out != nullptr || out.u_out != nullptr;
+        al.stream = st; al.kind = 1;
+        qp_lds(s, c.shared != 0, al);
+        // the flag build (nmpc_qpf.hip) for what it is validated on - at most two integrator steps, as k_team_as - else the default one
+        HIP_TRY(s, (hipError_t)launch_qp_kind(s, al, in, out));
+        if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));
+        s->last_B = B; s->solved = true; s->timed = s->timing; s->timed_fused = true; s->timed_split = false; s->last_split = false;
+        s->last_shared = c.shared != 0;
+        return 0;
+    }
+    // lane layout ([row][Bp] workspace): linearisation as a launch of its own, then the QP
+    HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // (the lane kernels make no active-set passes)
+    hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
+    HIP_TRY(s, hipGetLastError());
+    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[1], st));
+    if (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) {
+        CondWork<T> cw;
+        const int N2 = (s->cfg.qp_cond_N > 0 && s->cfg.qp_cond_N < s->cfg.N) ? s->cfg.qp_cond_N : s->cfg.N;
+        cond_layout(cw, s->cfg.N, N2);
+        cw.base = (T *)s->cond;
+        cw.Bp = s->Bp;
+        hipLaunchKernelGGL(k_cond_ipm<T>, grid, block, 0, st, c, w, cw, out, B);
     } else {
         hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
     }
@@ -862,7 +772,7 @@ static int launch(nmpc_solver *s, int B, const void *x0, const void *yref, const
     s->last_B = B;
     s->solved = true;
     s->timed = s->timing;
-    s->timed_fused = fused != 0;
+    s->timed_fused = false;
     s->timed_split = false;
     s->last_split = false;
     s->last_shared = c.shared != 0;
@@ -882,10 +792,7 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     hipStream_t st = (hipStream_t)hip_stream;
     if (s->cfg.dtype == NMPC_DTYPE_F32IO) return launch_f32io(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
-    int rc = s->cfg.dtype == NMPC_DTYPE_F64
-                 ? launch<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st)
-                 : launch<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
-    return rc;
+    return launch_f64(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
 }
 
 static int ensure_staging(nmpc_solver *s, size_t B)
@@ -1251,7 +1158,7 @@ int nmpc_block_factor_device(nmpc_solver *s, int B, int blocks, const void *x0, 
     if (B < 1 || B > s->cfg.max_batch || !x0 || !yref || !yref_e) return s->fail(NMPC_EARG, "block_factor: bad arguments");
     if (blocks < 1 || blocks > N) return s->fail(NMPC_EARG, "block_factor: blocks=%d outside [1, N=%d]", blocks, N);
     if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "block_factor: x_init and u_init must both be given or both be NULL");
-    if (s->cfg.dtype == NMPC_DTYPE_F32 || !(s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) || (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) || !s->tAB)
+    if (!(s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) || (s->cfg.flags & NMPC_FLAG_CONDENSED_QP) || !s->tAB)
         return s->fail(NMPC_EARG, "block_factor: FP64 arithmetic in the team mapping only");
     if (!s->solved || s->last_B < B) return s->fail(NMPC_EARG, "block_factor: no solve of >= %d instances on this handle yet", B);
     if (x_init == nullptr && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START))

@@ -25,7 +25,7 @@ struct CondWork {
     int Bp, N2, BS, NUB;           // blocks, max stages per block, max inputs per block
     // row offsets
     int blk0, blk_stride;          // per-block region
-    int oA, oB, ob, oQ, oS, oR, oq, orr, oL, oM, om, oU, oLL, oLU, oUA, oDU, oLO, oHI, oIN, in_stride;
+    int oA, oB, ob, oQ, oS, oR, oq, orr, oL, oM, om, oU, oLL, oLU, oUA, oDU, oLO, oHI, oTL, oTU, oBS, oQS, oIN, in_stride;
     int oP, oT, oPA, oPB, oV, oXH; // per-lane scratch
     int rows;
 };
@@ -52,6 +52,8 @@ inline int cond_layout(CondWork<T> &cw, int N, int N2)
     cw.om = o; o += nub;
     cw.oU = o; o += nub; cw.oLL = o; o += nub; cw.oLU = o; o += nub; cw.oUA = o; o += nub;
     cw.oDU = o; o += nub; cw.oLO = o; o += nub; cw.oHI = o; o += nub;
+    cw.oTL = o; o += nub; cw.oTU = o; o += nub;      // slacks of the input bounds: iterates of the interior point (oracle ocpqp_ipm)
+    cw.oBS = o; o += NX; cw.oQS = o; o += NX;        // b + B u and q + S'u of the iterate: the Newton system is solved for the input STEP
     cw.oIN = o; cw.in_stride = NX * NX + NX * nub + NX; o += (cw.BS + 1) * cw.in_stride;
     cw.blk0 = 0; cw.blk_stride = o;
     int s = N2 * o;
@@ -182,6 +184,8 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
             if (v - lo < thr) v = lo + thr;
             if (hi - v < thr) v = hi - thr;
             CWV(o + cw.oU + i) = v;
+            CWV(o + cw.oTL + i) = v - lo;
+            CWV(o + cw.oTU + i) = hi - v;
             CWV(o + cw.oLL + i) = c.mu0 / (v - lo);
             CWV(o + cw.oLU + i) = c.mu0 / (hi - v);
         }
@@ -204,7 +208,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
             for (int i = 0; i < NX; i++) {
                 T s = CWV(vPV + i);
                 if (!homog)
-                    for (int l = 0; l < NX; l++) s += CWV(cw.oP + i * NX + l) * CWV(o + cw.ob + l);
+                    for (int l = 0; l < NX; l++) s += CWV(cw.oP + i * NX + l) * CWV(o + cw.oBS + l);
                 CWV(vH + i) = s;
             }
             if (factor) {
@@ -221,7 +225,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
                     }
                 }
                 for (int i = 0; i < nub; i++) {
-                    const T tl = CWV(o + cw.oU + i) - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - CWV(o + cw.oU + i);
+                    const T tl = CWV(o + cw.oTL + i), tu = CWV(o + cw.oTU + i);
                     const T sg = CWV(o + cw.oLL + i) / tl + CWV(o + cw.oLU + i) / tu;
                     for (int l = 0; l < nub; l++) {
                         T s = CWV(o + cw.oR + i * nubm + l) + (i == l ? sg : T(0));
@@ -277,7 +281,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
                 CWV(o + cw.om + i) = s / CWV(o + cw.oL + i * nubm + i);
             }
             for (int i = 0; i < NX; i++) {
-                T s = homog ? T(0) : CWV(o + cw.oq + i);
+                T s = homog ? T(0) : CWV(o + cw.oQS + i);
                 for (int t = 0; t < NX; t++) s += CWV(o + cw.oA + t * NX + i) * CWV(vH + t);
                 CWV(vGX + i) = s;
             }
@@ -306,7 +310,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
             }
             for (int i = 0; i < nub; i++) CWV(o + dst + i) = CWV(vGU + i);
             for (int i = 0; i < NX; i++) {
-                T s = homog ? T(0) : CWV(o + cw.ob + i);
+                T s = homog ? T(0) : CWV(o + cw.oBS + i);
                 for (int l = 0; l < NX; l++) s += CWV(o + cw.oA + i * NX + l) * CWV(cw.oXH + ib * NX + l);
                 for (int l = 0; l < nub; l++) s += CWV(o + cw.oB + i * nubm + l) * CWV(vGU + l);
                 CWV(cw.oXH + (ib + 1) * NX + i) = s;
@@ -314,52 +318,71 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         }
     };
 
+    // one bound pair of the iterate: carried slacks, bound residuals (zero to rounding), and the affine directions of slacks and multipliers
+    // for an affine input step d (oracle ocpqp_ipm: el, eu, dla, dua)
+    struct PairC { T u, ll, lu, tl, tu, rl, ru; };
+    auto pair_at = [&](int o, int i) {
+        PairC p;
+        p.u = CWV(o + cw.oU + i); p.ll = CWV(o + cw.oLL + i); p.lu = CWV(o + cw.oLU + i);
+        p.tl = CWV(o + cw.oTL + i); p.tu = CWV(o + cw.oTU + i);
+        p.rl = (p.u - CWV(o + cw.oLO + i)) - p.tl;
+        p.ru = (CWV(o + cw.oHI + i) - p.u) - p.tu;
+        return p;
+    };
     for (;;) {
         mu = 0;
         for (int ib = 0; ib < N2; ib++) {
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
-            for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i);
-                mu += CWV(o + cw.oLL + i) * (u - CWV(o + cw.oLO + i)) + CWV(o + cw.oLU + i) * (CWV(o + cw.oHI + i) - u);
-            }
+            for (int i = 0; i < nub; i++)
+                mu += CWV(o + cw.oLL + i) * CWV(o + cw.oTL + i) + CWV(o + cw.oLU + i) * CWV(o + cw.oTU + i);
         }
         mu /= nc;
         if (!(mu == mu)) { status = 1; break; }
         if (mu <= c.tol_comp && rho <= c.tol_stat) break;
         if (it >= c.iter_max) { status = 2; break; }
         it++;
-        for (int ib = 0; ib < N2; ib++) {   // affine rhs into oDU
+        for (int ib = 0; ib < N2; ib++) {   // input-step form of the block (b + B u, q + S'u) and the affine rhs r + R u + residual terms into oDU
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
+            for (int i = 0; i < NX; i++) {
+                T sb = CWV(o + cw.ob + i), sq = CWV(o + cw.oq + i);
+                for (int l = 0; l < nub; l++) {
+                    const T ul = CWV(o + cw.oU + l);
+                    sb += CWV(o + cw.oB + i * nubm + l) * ul;
+                    sq += CWV(o + cw.oS + l * NX + i) * ul;
+                }
+                CWV(o + cw.oBS + i) = sb;
+                CWV(o + cw.oQS + i) = sq;
+            }
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u;
-                const T sg = CWV(o + cw.oLL + i) / tl + CWV(o + cw.oLU + i) / tu;
-                CWV(o + cw.oDU + i) = CWV(o + cw.orr + i) - sg * u;
+                const PairC p = pair_at(o, i);
+                T sr = CWV(o + cw.orr + i);
+                for (int l = 0; l < nub; l++) sr += CWV(o + cw.oR + i * nubm + l) * CWV(o + cw.oU + l);
+                CWV(o + cw.oDU + i) = sr + p.ll / p.tl * p.rl - p.lu / p.tu * p.ru;
             }
         }
         if (!backward(true, false)) { status = 3; break; }
-        forward(false, cw.oUA);
+        forward(false, cw.oUA);              // oUA: the affine STEP of the inputs
         T aaff = T(1);
         for (int ib = 0; ib < N2; ib++) {
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i), ll = CWV(o + cw.oLL + i), lu = CWV(o + cw.oLU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u, d = CWV(o + cw.oUA + i) - u;
-                const T dla = -ll - ll / tl * d, dua = -lu + lu / tu * d;
-                if (d < T(0) && -tl / d < aaff) aaff = -tl / d;
-                if (d > T(0) && tu / d < aaff) aaff = tu / d;
-                if (dla < T(0) && -ll / dla < aaff) aaff = -ll / dla;
-                if (dua < T(0) && -lu / dua < aaff) aaff = -lu / dua;
+                const PairC p = pair_at(o, i);
+                const T d = CWV(o + cw.oUA + i), el = d + p.rl, eu = -d + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                if (el < T(0) && -p.tl / el < aaff) aaff = -p.tl / el;
+                if (eu < T(0) && -p.tu / eu < aaff) aaff = -p.tu / eu;
+                if (dla < T(0) && -p.ll / dla < aaff) aaff = -p.ll / dla;
+                if (dua < T(0) && -p.lu / dua < aaff) aaff = -p.lu / dua;
             }
         }
         T muaff = 0;
         for (int ib = 0; ib < N2; ib++) {
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i), ll = CWV(o + cw.oLL + i), lu = CWV(o + cw.oLU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u, d = CWV(o + cw.oUA + i) - u;
-                const T dla = -ll - ll / tl * d, dua = -lu + lu / tu * d;
-                muaff += (ll + aaff * dla) * (tl + aaff * d) + (lu + aaff * dua) * (tu - aaff * d);
+                const PairC p = pair_at(o, i);
+                const T d = CWV(o + cw.oUA + i), el = d + p.rl, eu = -d + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                muaff += (p.ll + aaff * dla) * (p.tl + aaff * el) + (p.lu + aaff * dua) * (p.tu + aaff * eu);
             }
         }
         muaff /= nc;
@@ -369,11 +392,11 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         for (int ib = 0; ib < N2; ib++) {   // corrector rhs into oDU
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i), ll = CWV(o + cw.oLL + i), lu = CWV(o + cw.oLU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u, da = CWV(o + cw.oUA + i) - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                const T cl = dla * da, cu = -dua * da;
-                CWV(o + cw.oDU + i) = -(sigmu - cl) / tl + (sigmu - cu) / tu;
+                const PairC p = pair_at(o, i);
+                const T da = CWV(o + cw.oUA + i), el = da + p.rl, eu = -da + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                const T cl = dla * el, cu = dua * eu;
+                CWV(o + cw.oDU + i) = -(sigmu - cl) / p.tl + (sigmu - cu) / p.tu;
             }
         }
         backward(false, true);
@@ -382,18 +405,19 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         for (int ib = 0; ib < N2; ib++) {
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i), ll = CWV(o + cw.oLL + i), lu = CWV(o + cw.oLU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u, da = CWV(o + cw.oUA + i) - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                const T cl = dla * da, cu = -dua * da;
+                const PairC p = pair_at(o, i);
+                const T da = CWV(o + cw.oUA + i), el = da + p.rl, eu = -da + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                const T cl = dla * el, cu = dua * eu;
                 const T d = da + CWV(o + cw.oDU + i);
                 CWV(o + cw.oDU + i) = d;
-                const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                if (d < T(0) && -tl / d < amax) amax = -tl / d;
-                if (d > T(0) && tu / d < amax) amax = tu / d;
-                if (dl < T(0) && -ll / dl < amax) amax = -ll / dl;
-                if (du < T(0) && -lu / du < amax) amax = -lu / du;
+                const T dtl = d + p.rl, dtu = -d + p.ru;
+                const T dl = -(p.ll * p.tl + cl - sigmu) / p.tl - p.ll / p.tl * dtl;
+                const T du = -(p.lu * p.tu + cu - sigmu) / p.tu - p.lu / p.tu * dtu;
+                if (dtl < T(0) && -p.tl / dtl < amax) amax = -p.tl / dtl;
+                if (dtu < T(0) && -p.tu / dtu < amax) amax = -p.tu / dtu;
+                if (dl < T(0) && -p.ll / dl < amax) amax = -p.ll / dl;
+                if (du < T(0) && -p.lu / du < amax) amax = -p.lu / du;
             }
         }
         T alpha = c.tau * amax;
@@ -403,16 +427,19 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         for (int ib = 0; ib < N2; ib++) {
             const int o = cw.blk0 + ib * cw.blk_stride, nub = NU * bsz(ib);
             for (int i = 0; i < nub; i++) {
-                const T u = CWV(o + cw.oU + i), ll = CWV(o + cw.oLL + i), lu = CWV(o + cw.oLU + i);
-                const T tl = u - CWV(o + cw.oLO + i), tu = CWV(o + cw.oHI + i) - u, da = CWV(o + cw.oUA + i) - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                const T cl = dla * da, cu = -dua * da;
+                const PairC p = pair_at(o, i);
+                const T da = CWV(o + cw.oUA + i), el = da + p.rl, eu = -da + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                const T cl = dla * el, cu = dua * eu;
                 const T d = CWV(o + cw.oDU + i);
-                const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                CWV(o + cw.oU + i) = u + alpha * d;
-                CWV(o + cw.oLL + i) = ll + alpha * dl;
-                CWV(o + cw.oLU + i) = lu + alpha * du;
+                const T dtl = d + p.rl, dtu = -d + p.ru;
+                const T dl = -(p.ll * p.tl + cl - sigmu) / p.tl - p.ll / p.tl * dtl;
+                const T du = -(p.lu * p.tu + cu - sigmu) / p.tu - p.lu / p.tu * dtu;
+                CWV(o + cw.oU + i) = p.u + alpha * d;
+                CWV(o + cw.oTL + i) = p.tl + alpha * dtl;
+                CWV(o + cw.oTU + i) = p.tu + alpha * dtu;
+                CWV(o + cw.oLL + i) = p.ll + alpha * dl;
+                CWV(o + cw.oLU + i) = p.lu + alpha * du;
             }
         }
         rho *= (T(1) - alpha);

@@ -9,11 +9,12 @@
 //
 // Same algorithm, same update rules and the same constants as oracle/nmpc_oracle.c
 // (ocpqp_ipm), restated for one-instance-per-lane execution:
-//   * feasible start in the inputs: slacks are t_l = u - lo, t_u = hi - u by construction,
-//     states are implied by the affine dynamics -> the only residuals are stationarity
-//     (shrinks by 1-alpha per step, tracked as rho) and complementarity (mu);
-//   * each Newton system is an LQ problem in "absolute" form, solved by one backward and
-//     one forward Riccati sweep; the corrector re-uses the factorisation through a
+//   * feasible start in the inputs; the slacks t_l, t_u of the input bounds are ITERATES of their own (HPIPM's form:
+//     t <- t + alpha dt, never re-formed as u - lo), states are implied by the affine dynamics -> the residuals that
+//     matter are stationarity (shrinks by 1-alpha per step, tracked as rho) and complementarity (mu);
+//   * each Newton system is an LQ problem - absolute in the states, solved for the STEP of the inputs (u = u_it + w: the
+//     direction of a nearly active input must resolve its 1e-14 slack, which a target ua with d = ua - u cannot) - by one
+//     backward and one forward Riccati sweep; the corrector re-uses the factorisation through a
 //     homogeneous sweep for the change of the input gradient;
 //   * the primal-dual update of an iteration is applied lazily inside the next backward
 //     sweep, so the small per-stage vectors cross memory once per sweep.
@@ -89,14 +90,6 @@ NMPC_HD void lane_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> 
         }
         NMPC_UNROLL for (int i = 0; i < NX; i++)
             NMPC_ST(w.bv, k * NX + i, xn[i] - NMPC_LD(w.xl, (k + 1) * NX + i));
-        if (w.tAB) {   // row-major per-instance copy for the team kernel (nmpc_team.hpp)
-            T *a = w.tAB + ((size_t)lane * Ns + k) * TAB_ROWS;
-            NMPC_UNROLL for (int i = 0; i < NX; i++) {
-                NMPC_UNROLL for (int cc = 0; cc < 8; cc++) a[i * 8 + cc] = (cc < NZ && i < ad_rows(cc)) ? S[cc][i] : T(0);
-                NMPC_UNROLL for (int j = 0; j < NU; j++) a[104 + i * NU + j] = S[7 + j][i];
-                a[156 + i] = xn[i] - NMPC_LD(w.xl, (k + 1) * NX + i);
-            }
-        }
     }
 }
 
@@ -122,6 +115,8 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
             if (v - lo < thr) v = lo + thr;
             if (hi - v < thr) v = hi - thr;
             NMPC_ST(ivk, i, v);
+            NMPC_ST(ivk, IV_TL + i, v - lo);
+            NMPC_ST(ivk, IV_TU + i, hi - v);
             NMPC_ST(ivk, 4 + i, c.mu0 / (v - lo));
             NMPC_ST(ivk, 8 + i, c.mu0 / (hi - v));
         }
@@ -130,6 +125,26 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
     T mu = c.mu0, rho = T(1), alpha = 0, sigmu = 0;
     int it = 0, status = 0;
     bool pending = false;
+    // one bound pair of the iterate as a sweep sees it (oracle ocpqp_ipm): carried slacks, bound residuals (zero to rounding)
+    struct PairL { T u, ll, lu, tl, tu, rl, ru; };
+    auto pair_at = [&](const T *ivk, int k, int i) {
+        PairL p;
+        const T ul = NMPC_LD(w.ul, k * NU + i);
+        p.u = NMPC_LD(ivk, i); p.ll = NMPC_LD(ivk, 4 + i); p.lu = NMPC_LD(ivk, 8 + i);
+        p.tl = NMPC_LD(ivk, IV_TL + i); p.tu = NMPC_LD(ivk, IV_TU + i);
+        p.rl = (p.u - (c.lbu[i] - ul)) - p.tl;
+        p.ru = ((c.ubu[i] - ul) - p.u) - p.tu;
+        return p;
+    };
+    // full direction of the pair for the affine step da and the final step d (slots 12.., 16.. of the iterate row)
+    auto step_of = [&](const PairL &p, T da, T d, T &dtl, T &dtu, T &dl, T &du) {
+        const T el = da + p.rl, eu = -da + p.ru;
+        const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+        const T cl = dla * el, cu = dua * eu;
+        dtl = d + p.rl; dtu = -d + p.ru;
+        dl = -(p.ll * p.tl + cl - sigmu) / p.tl - p.ll / p.tl * dtl;
+        du = -(p.lu * p.tu + cu - sigmu) / p.tu - p.lu / p.tu * dtu;
+    };
 
     for (;;) {
         if (!(mu == mu)) { status = 1; break; }
@@ -145,54 +160,49 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
         T musum = 0;
         for (int k = N - 1; k >= 0; k--) {
             T *ivk = w.iv + k * ivs_;
-            T D[NU], rh[NU];
+            T D[NU], rh[NU], ush[NU];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                const T ul = NMPC_LD(w.ul, k * NU + i);
-                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
-                T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                PairL p = pair_at(ivk, k, i);
                 if (pending) {
-                    const T tl = u - lo, tu = hi - u;
-                    const T da = NMPC_LD(ivk, 12 + i) - u, d = NMPC_LD(ivk, 16 + i);
-                    const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                    const T cl = dla * da, cu = -dua * da;
-                    const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                    const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                    u += alpha * d; ll += alpha * dl; lu += alpha * du;
-                    NMPC_ST(ivk, i, u); NMPC_ST(ivk, 4 + i, ll); NMPC_ST(ivk, 8 + i, lu);
+                    T dtl, dtu, dl, du;
+                    step_of(p, NMPC_LD(ivk, 12 + i), NMPC_LD(ivk, 16 + i), dtl, dtu, dl, du);
+                    NMPC_ST(ivk, i, p.u + alpha * NMPC_LD(ivk, 16 + i));
+                    NMPC_ST(ivk, IV_TL + i, p.tl + alpha * dtl); NMPC_ST(ivk, IV_TU + i, p.tu + alpha * dtu);
+                    NMPC_ST(ivk, 4 + i, p.ll + alpha * dl); NMPC_ST(ivk, 8 + i, p.lu + alpha * du);
+                    p = pair_at(ivk, k, i);
                 }
-                const T tl = u - lo, tu = hi - u;
-                musum += ll * tl + lu * tu;
-                const T sg = ll / tl + lu / tu;
+                musum += p.ll * p.tl + p.lu * p.tu;
+                const T sg = p.ll / p.tl + p.lu / p.tu;
                 D[i] = c.Rd[i] + sg;
-                rh[i] = NMPC_LD(w.qr, k * QR_ROWS + NX + i) - sg * u;
+                ush[i] = p.u;
+                rh[i] = NMPC_LD(w.qr, k * QR_ROWS + NX + i) + c.Rd[i] * p.u + p.ll / p.tl * p.rl - p.lu / p.tu * p.ru;
             }
             ok &= ricc_factor_stage(c, P, pv, w.AB + k * abs_, w.bv + k * bs_, w.qr + (size_t)k * QR_ROWS * Bp,
-                                    D, rh, w.LM + k * lms_, Bp, lane, k == 0);
+                                    D, rh, w.LM + k * lms_, Bp, lane, k == 0, ush);
         }
         pending = false;
         NMPC_STAMP(0)
         mu = musum / nc;   // exact duality measure of the current iterate
         if (!ok) { status = (mu == mu) ? 4 : 1; break; }
-        // ---- sweep B: forward affine solve, step length and mu of the affine step
-        T xh[NX], uh[NU];
+        // ---- sweep B: forward affine solve (the STEP of the inputs), step length and mu of the affine step
+        T xh[NX], uh[NU], ush[NU];
         NMPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = 0;
         T aaff = T(1), s2 = 0;
         for (int k = 0; k < N; k++) {
             T *ivk = w.iv + k * ivs_;
+            NMPC_UNROLL for (int i = 0; i < NU; i++) ush[i] = NMPC_LD(ivk, i);
             ricc_forward_stage(c, xh, uh, w.AB + k * abs_, w.bv + k * bs_, w.LM + k * lms_, Bp, lane,
-                               true, k == 0, k == N - 1);
+                               true, k == 0, k == N - 1, ush);
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                const T ul = NMPC_LD(w.ul, k * NU + i);
-                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
-                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
+                const PairL p = pair_at(ivk, k, i);
                 NMPC_ST(ivk, 12 + i, uh[i]);
-                const T tl = u - lo, tu = hi - u, d = uh[i] - u;
-                const T dla = -ll - ll / tl * d, dua = -lu + lu / tu * d;
-                if (d < T(0) && -tl / d < aaff) aaff = -tl / d;
-                if (d > T(0) && tu / d < aaff) aaff = tu / d;
-                if (dla < T(0) && -ll / dla < aaff) aaff = -ll / dla;
-                if (dua < T(0) && -lu / dua < aaff) aaff = -lu / dua;
-                s2 += dla * d - dua * d;
+                const T el = uh[i] + p.rl, eu = -uh[i] + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                if (el < T(0) && -p.tl / el < aaff) aaff = -p.tl / el;
+                if (eu < T(0) && -p.tu / eu < aaff) aaff = -p.tu / eu;
+                if (dla < T(0) && -p.ll / dla < aaff) aaff = -p.ll / dla;
+                if (dua < T(0) && -p.lu / dua < aaff) aaff = -p.lu / dua;
+                s2 += dla * el + dua * eu;
             }
         }
         NMPC_STAMP(1)
@@ -207,13 +217,12 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
             T *ivk = w.iv + k * ivs_;
             T dr[NU];
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                const T ul = NMPC_LD(w.ul, k * NU + i);
-                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
-                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
-                const T tl = u - lo, tu = hi - u, da = NMPC_LD(ivk, 12 + i) - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                const T cl = dla * da, cu = -dua * da;
-                dr[i] = -(sigmu - cl) / tl + (sigmu - cu) / tu;
+                const PairL p = pair_at(ivk, k, i);
+                const T da = NMPC_LD(ivk, 12 + i);
+                const T el = da + p.rl, eu = -da + p.ru;
+                const T dla = -p.ll - p.ll / p.tl * el, dua = -p.lu - p.lu / p.tu * eu;
+                const T cl = dla * el, cu = dua * eu;
+                dr[i] = -(sigmu - cl) / p.tl + (sigmu - cu) / p.tu;
             }
             ricc_back_homog_stage(c, pv, w.AB + k * abs_, dr, w.LM + k * lms_, Bp, lane, k == 0);
         }
@@ -226,20 +235,15 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
             ricc_forward_stage(c, xh, uh, w.AB + k * abs_, w.bv + k * bs_, w.LM + k * lms_, Bp, lane,
                                false, k == 0, k == N - 1);
             NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                const T ul = NMPC_LD(w.ul, k * NU + i);
-                const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
-                const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
-                const T tl = u - lo, tu = hi - u, da = NMPC_LD(ivk, 12 + i) - u;
-                const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                const T cl = dla * da, cu = -dua * da;
-                const T d = da + uh[i];
+                const PairL p = pair_at(ivk, k, i);
+                const T da = NMPC_LD(ivk, 12 + i), d = da + uh[i];
                 NMPC_ST(ivk, 16 + i, d);
-                const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                if (d < T(0) && -tl / d < amax) amax = -tl / d;
-                if (d > T(0) && tu / d < amax) amax = tu / d;
-                if (dl < T(0) && -ll / dl < amax) amax = -ll / dl;
-                if (du < T(0) && -lu / du < amax) amax = -lu / du;
+                T dtl, dtu, dl, du;
+                step_of(p, da, d, dtl, dtu, dl, du);
+                if (dtl < T(0) && -p.tl / dtl < amax) amax = -p.tl / dtl;
+                if (dtu < T(0) && -p.tu / dtu < amax) amax = -p.tu / dtu;
+                if (dl < T(0) && -p.ll / dl < amax) amax = -p.ll / dl;
+                if (du < T(0) && -p.lu / du < amax) amax = -p.lu / du;
             }
         }
         NMPC_STAMP(3)
@@ -256,16 +260,10 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
             for (int k = 0; k < N; k++) {
                 T *ivk = w.iv + k * ivs_;
                 NMPC_UNROLL for (int i = 0; i < NU; i++) {
-                    const T ul = NMPC_LD(w.ul, k * NU + i);
-                    const T lo = c.lbu[i] - ul, hi = c.ubu[i] - ul;
-                    const T u = NMPC_LD(ivk, i), ll = NMPC_LD(ivk, 4 + i), lu = NMPC_LD(ivk, 8 + i);
-                    const T tl = u - lo, tu = hi - u;
-                    const T da = NMPC_LD(ivk, 12 + i) - u, d = NMPC_LD(ivk, 16 + i);
-                    const T dla = -ll - ll / tl * da, dua = -lu + lu / tu * da;
-                    const T cl = dla * da, cu = -dua * da;
-                    const T dl = -(ll * tl + cl - sigmu) / tl - ll / tl * d;
-                    const T du = -(lu * tu + cu - sigmu) / tu + lu / tu * d;
-                    ms += (ll + alpha * dl) * (tl + alpha * d) + (lu + alpha * du) * (tu - alpha * d);
+                    const PairL p = pair_at(ivk, k, i);
+                    T dtl, dtu, dl, du;
+                    step_of(p, NMPC_LD(ivk, 12 + i), NMPC_LD(ivk, 16 + i), dtl, dtu, dl, du);
+                    ms += (p.ll + alpha * dl) * (p.tl + alpha * dtl) + (p.lu + alpha * du) * (p.tu + alpha * dtu);
                 }
             }
             mu = ms / nc;

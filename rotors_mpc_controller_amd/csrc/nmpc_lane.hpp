@@ -39,9 +39,11 @@ constexpr int NZ = 7;                 // stored columns of A: q (4) and omega (3
 constexpr int AD_SIZE = 79;           // 4*10 + 3*13
 constexpr int AB_ROWS = AD_SIZE + NX * NU;   // 131 rows per stage in the AB array
 constexpr int LM_ROWS = 10 + NU * NX + NU;   // L (10, diagonal stored inverted) + M (52) + m (4)
-constexpr int IV_ROWS = 36;           // u, lam_l, lam_u, u_aff, du  (4 each) | 4 spare slots: where lanes that carry no input of
+constexpr int IV_ROWS = 44;           // u, lam_l, lam_u, affine step, step  (4 each) | 4 spare slots: where lanes that carry no input of
                                       // their own store, so that no store of a tile-form sweep is predicated | u, lam_l, lam_u of the warm start an exhausted
-                                      // active-set attempt leaves for the interior point (4 each)
+                                      // active-set attempt leaves for the interior point (4 each) | t_l, t_u: the slacks of the input bounds, iterates of the
+                                      // interior point (4 each; round 5 - HPIPM's form, oracle ocpqp_ipm)
+constexpr int IV_TL = 36, IV_TU = 40;
 constexpr int QR_ROWS = NX + NU;      // q_k (13), r_k (4)
 
 NMPC_HD constexpr int ad_rows(int c) { return c < 4 ? 10 : 13; }
@@ -373,8 +375,10 @@ NMPC_HD float nmpc_rsqrt(float v) { return 1.0f / sqrtf(v); }
 template <class T>
 NMPC_HD bool ricc_factor_stage(const Consts<T> &c, T *P, T *pv, const T *ABk, const T *bk,
                                const T *qk, const T *D, const T *rhat, T *LMk, int Bp, int lane,
-                               bool first)
+                               bool first, const T *ush = nullptr)
 {
+    // ush (nullable): inputs of the interior point's iterate - the stage is then solved for the input STEP w, u = ush + w:
+    // x+ = A x + B w + (b + B ush); rhat is the caller's business (r + R ush + ...)
     bool ok = true;
     T Bm[NX][NU], PB[NX][NU], h[NX];
     load_b(ABk, Bp, lane, Bm);
@@ -389,6 +393,11 @@ NMPC_HD bool ricc_factor_stage(const Consts<T> &c, T *P, T *pv, const T *ABk, co
     {
         T bb[NX];
         NMPC_UNROLL for (int i = 0; i < NX; i++) bb[i] = NMPC_LD(bk, i);
+        if (ush) {
+            NMPC_UNROLL for (int i = 0; i < NX; i++) {
+                NMPC_UNROLL for (int j = 0; j < NU; j++) bb[i] += Bm[i][j] * ush[j];
+            }
+        }
         NMPC_UNROLL for (int i = 0; i < NX; i++) {
             T a = pv[i];
             NMPC_UNROLL for (int l = 0; l < NX; l++) a += P[sidx(i, l)] * bb[l];
@@ -543,8 +552,9 @@ NMPC_HD void ricc_back_homog_stage(const Consts<T> &c, T *pv, const T *ABk, cons
 // Forward stage: uh = -L^{-T}(M xh + m); xh <- A xh + B uh (+ b).  `zero_x`: xh is known to be 0.
 template <class T>
 NMPC_HD void ricc_forward_stage(const Consts<T> &c, T *xh, T *uh, const T *ABk, const T *bk,
-                                const T *LMk, int Bp, int lane, bool with_b, bool zero_x, bool last)
+                                const T *LMk, int Bp, int lane, bool with_b, bool zero_x, bool last, const T *ush = nullptr)
 {
+    // ush (nullable): uh is the input STEP from the iterate ush (see ricc_factor_stage); the state moves with ush + uh
     T Lf[10];
     NMPC_UNROLL for (int i = 0; i < 10; i++) Lf[i] = NMPC_LD(LMk, i);
     NMPC_UNROLL for (int i = 0; i < NU; i++) {
@@ -560,7 +570,9 @@ NMPC_HD void ricc_forward_stage(const Consts<T> &c, T *xh, T *uh, const T *ABk, 
     load_ad(ABk, Bp, lane, Ad);
     load_b(ABk, Bp, lane, Bm);
     NMPC_UNROLL for (int i = 0; i < NX; i++) y[i] = with_b ? NMPC_LD(bk, i) : T(0);
-    a_mul_add(c, Ad, Bm, xh, uh, y);
+    T uu[NU];
+    NMPC_UNROLL for (int i = 0; i < NU; i++) uu[i] = ush ? ush[i] + uh[i] : uh[i];
+    a_mul_add(c, Ad, Bm, xh, uu, y);
     NMPC_UNROLL for (int i = 0; i < NX; i++) xh[i] = y[i];
 }
 

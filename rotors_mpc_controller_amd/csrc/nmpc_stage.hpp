@@ -10,7 +10,8 @@
 //     H = D + Bm'Pbar Bm = L Dh L' (unit L),   X = Bm'Pbar Abar + rhat e15',   M0 = L^-1 X,   M = Dh^-1 M0,
 //     Pbar_k = Qbar + Abar'Pbar Abar - M0'M     (kept exactly symmetric: products above the diagonal, transposes below)
 // Variants (compile time): PINS - inputs marked active are pinned at their bounds (they leave B through a mask and enter b);
-// IPMV - barrier terms of an interior-point iteration on the input Hessian; both - the choice is a run-time flag per team (tail mode);
+// IPMV - barrier terms of an interior-point iteration on the input Hessian, the stage solved for the STEP of the inputs (the iterate's
+// inputs enter b like pinned values); both - the choice is a run-time flag per team (tail mode);
 // LAST - stage 0 of a sweep whose value is not needed (no Riccati update).
 // What a caller does around it: operand prefetch, the stores of the factors / gradient rows / checkpoints (through the sink), pass logic.
 #pragma once
@@ -38,7 +39,9 @@ struct StageIn {
     double q_r;             // W_q (x_lin - yref_x) of natural row rr
     double ul, ulc;         // linearisation input of components a | c
     double pc, pca;         // pin codes of inputs c | a (PINS)
-    double u_it, ll_it, lu_it;   // iterate of input a (IPMV)
+    double u_it, ll_it, lu_it;   // iterate of input a (IPMV): input, multipliers of its two bounds ...
+    double tl_it, tu_it;         // ... and their slacks (iterates of their own)
+    double u_itc;                // iterate of input c (IPMV): the stage is solved for the input STEP, b_k + B_k u_it enters column 15 of Abar
 };
 
 struct StageOut {
@@ -75,11 +78,13 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
     const int ta = L.ta, tc = L.tc;
     T mask_a = T(1), mask_c = T(1), D_a = L.Rd_a, rhat_a = in.rk;
     if (IPMV) {
-        // barrier terms of the interior-point iteration: D = R + lam_l / t_l + lam_u / t_u, rhat = r - (D - R) u
-        const Pair<T> pr(in.u_it, in.ll_it, in.lu_it, L.lb_a - in.ul, L.ub_a - in.ul);
+        // barrier terms of the interior-point iteration, solved for the STEP w of the inputs (u = u_it + w; oracle ocpqp_ipm):
+        // D = R + lam_l / t_l + lam_u / t_u, rhat = r + R u_it + (lam_l / t_l) rl - (lam_u / t_u) ru, and b_k + B_k u_it in column 15 below
+        const Pair<T> pr(in.u_it, in.ll_it, in.lu_it, in.tl_it, in.tu_it, L.lb_a - in.ul, L.ub_a - in.ul);
         const T sg = pr.kl + pr.ku;
-        if (PINS) { D_a = ipm_on ? L.Rd_a + sg : D_a; rhat_a = ipm_on ? in.rk - sg * in.u_it : rhat_a; }
-        else { D_a = L.Rd_a + sg; rhat_a = in.rk - sg * in.u_it; }
+        const T rh = in.rk + L.Rd_a * in.u_it + pr.kl * pr.rl - pr.ku * pr.ru;
+        if (PINS) { D_a = ipm_on ? L.Rd_a + sg : D_a; rhat_a = ipm_on ? rh : rhat_a; }
+        else { D_a = L.Rd_a + sg; rhat_a = rh; }
     }
     bool any_pins = false;
     T (&Aq1)[4] = o.Aq1;
@@ -94,12 +99,17 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
         if (IPMV) { rhat_a = pinned_a ? -L.Rd_a * vpin_a : rhat_a; }
         else { D_a = L.Rd_a; rhat_a = pinned_a ? -L.Rd_a * vpin_a : in.rk; }
         any_pins = __ballot(pinned) != 0;
-        if (any_pins) {                          // pinned inputs enter through b (column 15 of Abar)
-            const T vp = pinned ? vpin_c : T(0);
+        if (any_pins || IPMV) {                  // pinned inputs - and the inputs of an interior-point iterate - enter through b (column 15 of Abar)
+            const T vp = (pinned ? vpin_c : T(0)) + ((IPMV && ipm_on) ? in.u_itc : T(0));
             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                 const T sm = quad_sum(Bt[kt] * vp);
                 if (tc == 3 && L.natR[kt] >= 0) Aq1[kt] += sm;
             }
+        }
+    } else if (IPMV) {
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {        // b_k + B_k u_it (column 15 of Abar): the iterate of input c sits in lane (a,c)
+            const T sm = quad_sum(Bt[kt] * in.u_itc);
+            if (tc == 3 && L.natR[kt] >= 0) Aq1[kt] += sm;
         }
     }
     // P B and Hr = B'PB first: the factorisation below depends on nothing else

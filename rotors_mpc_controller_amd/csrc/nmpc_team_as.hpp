@@ -445,8 +445,11 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         T n_xl = xlin(ks), n_ul = ulin(ks, cu);
         T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
         T n_pca = PINS ? tIV[ks * IV_ROWS + 16 + ta] : T(0), n_ulc = PINS ? ulin(ks, j) : T(0);
-        T n_u = 0, n_ll = 0, n_lu = 0;                       // the iterate of input a (interior-point variant)
-        if (IPMV) { n_u = tIV[ks * IV_ROWS + ta]; n_ll = tIV[ks * IV_ROWS + 4 + ta]; n_lu = tIV[ks * IV_ROWS + 8 + ta]; }
+        T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0, n_uc = 0;       // the iterate of input a - and the input of component c - (interior-point variant)
+        if (IPMV) {
+            const T *ivn = tIV + ks * IV_ROWS;
+            n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta]; n_uc = ivn[j];
+        }
         auto stage = [&](int k, auto last_tag, auto lds_tag) {
             constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
             constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
@@ -455,7 +458,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 if (!LAST) fetch_stage(k - 1, r);
             }
             T *lmk = tLM + k * TLM_ROWS;
-            const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu;
+            const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu, tl_it = n_tl, tu_it = n_tu, u_itc = n_uc;
             // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
             // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
             // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
@@ -467,10 +470,14 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 n_yx = (T)yr[(size_t)(k - 1) * NY + rr]; n_yu = (T)yr[(size_t)(k - 1) * NY + NX + cu];
                 n_xl = xlin(k - 1); n_ul = ulin(k - 1, cu);
                 if (PINS) { n_pc = tIV[(k - 1) * IV_ROWS + 16 + j]; n_pca = tIV[(k - 1) * IV_ROWS + 16 + ta]; n_ulc = ulin(k - 1, j); }
-                if (IPMV) { const T *ivn = tIV + (k - 1) * IV_ROWS; n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; }
+                if (IPMV) {
+                    const T *ivn = tIV + (k - 1) * IV_ROWS;
+                    n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta]; n_uc = ivn[j];
+                }
             }
             StageIn sin;
             sin.rk = rk; sin.q_r = q_r; sin.ul = ul; sin.ulc = ulc; sin.pc = pc; sin.pca = pca; sin.u_it = u_it; sin.ll_it = ll_it; sin.lu_it = lu_it;
+            sin.tl_it = tl_it; sin.tu_it = tu_it; sin.u_itc = u_itc;
             StageOut so;
             // the stage itself: nmpc_stage.hpp (one source for this sweep and the block sweeps of nmpc_block.hpp).  Stores happen where they
             // always did: gradient rows of pinned stages while X is formed, the factors as soon as M is final
@@ -543,7 +550,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         int xslot[4];
         NMPC_UNROLL for (int t = 0; t < 4; t++) xslot[t] = (tc == 0 && natR[t] >= 0) ? natR[t] : 13;
         const int cslot = tc == 0 ? 12 + ta : 20 + ta, pslot = tc == 0 ? 16 + ta : 20 + ta;
-        struct Ops { T mt[4], z, ul, pc, u, ll, lu, ab[SHARED ? 1 : 12]; };
+        struct Ops { T mt[4], z, ul, pc, u, ll, lu, tl, tu, ab[SHARED ? 1 : 12]; };
         const int kl = LDSC ? (lstg < N ? lstg : N) : 0;     // factors of stages [0, kl) come from LDS, [kl, N) from HBM
         // operands of stage kq from the HBM scratch (clamped index: prefetches run past the horizon).  Per-stage
         // linearisation: the stage tiles (transposed) travel with them - two to four stages ahead, where one stage
@@ -559,7 +566,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             }
             o.ul = ulin(k, ta);
             o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
-            if (IPMV) { const T *ivn = tIV + k * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; }
+            if (IPMV) { const T *ivn = tIV + k * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; }
             if (!SHARED) {
                 const T *a = tAB + (size_t)k * TAB_ROWS + rT;
                 NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
@@ -588,21 +595,24 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             const T v = mfma44(o.mt[2], xt[2], mfma44(o.mt[0], xt[0], T(0)))
                       + mfma44(o.mt[3], xt[3], mfma44(o.mt[1], xt[1], T(0)));
             const T ut = mfma44_na(o.z, v, T(0));                         // lane (a,0): u_a = -(L^-T v)_a
-            NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
             if constexpr (IPMV) {
-                // affine-scaling target of input a in lane (a,0): step-length terms of the predictor, target kept for the corrector
-                const T uj = ut;
+                // the sweep solved for the STEP of the inputs: the state moves with the iterate's input plus the step (lanes (a,0))
+                const T uf = ut + (tc == 0 ? o.u : T(0));
+                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], uf, xn[it]);
+                // affine-scaling step of input a in lane (a,0): step-length terms of the predictor, step kept for the corrector
+                const T d = ut;
                 const T lo = lb_a - ul, hi = ub_a - ul;
-                const Pair<T> pr(o.u, o.ll, o.lu, lo, hi);
-                const T d = uj - o.u;
-                const T dla = -o.ll - pr.kl * d, dua = -o.lu + pr.ku * d;
-                // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
-                const T a1 = d * pr.itl, a2 = d * pr.itu;
-                rmaxB = fmax(rmaxB, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
-                s2B += dla * d - dua * d;
-                ivk[cslot] = uj;
+                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lo, hi);
+                const T el = d + pr.rl, eu = pr.ru - d;                     // affine directions of the two slacks
+                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
+                // inverse step lengths: -el/tl, -eu/tu, -dla/ll = 1 + el/tl, -dua/lu = 1 + eu/tu
+                const T a1 = el * pr.itl, a2 = eu * pr.itu;
+                rmaxB = fmax(rmaxB, fmax(fmax(-a1, -a2), fmax(T(1) + a1, T(1) + a2)));
+                s2B += dla * el + dua * eu;
+                ivk[cslot] = d;
                 (void)pc;
             } else {
+                NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
                 // KKT check of the pass, input a in lane (a,0): a free input must sit inside its box; a pinned one
                 // must have a multiplier of the right sign (gradient from the rows the factor sweep left)
                 const T uj = ut;
@@ -672,24 +682,24 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             if (kl > 0) {
                 Ops ol;
                 T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
-                T n_u = 0, n_ll = 0, n_lu = 0, m_u = 0, m_ll = 0, m_lu = 0;      // interior-point variant: the iterate two stages ahead
+                T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0, m_u = 0, m_ll = 0, m_lu = 0, m_tl = 0, m_tu = 0;      // interior-point variant: the iterate two stages ahead
                 if (IPMV) {
-                    n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta];
+                    n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta]; n_tl = tIV[IV_TL + ta]; n_tu = tIV[IV_TU + ta];
                     const T *iv1 = tIV + (1 < N ? 1 : 0) * IV_ROWS;
-                    m_u = iv1[ta]; m_ll = iv1[4 + ta]; m_lu = iv1[8 + ta];
+                    m_u = iv1[ta]; m_ll = iv1[4 + ta]; m_lu = iv1[8 + ta]; m_tl = iv1[IV_TL + ta]; m_tu = iv1[IV_TU + ta];
                 }
                 // the factors of stage k + 1 leave LDS before stage k computes (two operand sets, alternating): a stage is a short
                 // chain of dependent MFMAs and would otherwise open with an exposed LDS round trip
                 Ops ol2;
                 auto scalars = [&](Ops &o, int k) {
-                    o.ul = n_ul; o.pc = n_pc; o.u = n_u; o.ll = n_ll; o.lu = n_lu;
+                    o.ul = n_ul; o.pc = n_pc; o.u = n_u; o.ll = n_ll; o.lu = n_lu; o.tl = n_tl; o.tu = n_tu;
                     const int kn = k + 1 < N ? k + 1 : k;
                     n_ul = ulin(kn, ta);
                     if (PINS) n_pc = tIV[kn * IV_ROWS + 16 + ta];
                     if (IPMV) {
-                        n_u = m_u; n_ll = m_ll; n_lu = m_lu;
+                        n_u = m_u; n_ll = m_ll; n_lu = m_lu; n_tl = m_tl; n_tu = m_tu;
                         const T *ivn = tIV + (k + 2 < N ? k + 2 : N - 1) * IV_ROWS;
-                        m_u = ivn[ta]; m_ll = ivn[4 + ta]; m_lu = ivn[8 + ta];
+                        m_u = ivn[ta]; m_ll = ivn[4 + ta]; m_lu = ivn[8 + ta]; m_tl = ivn[IV_TL + ta]; m_tu = ivn[IV_TU + ta];
                     }
                 };
                 fetch_ops_lds(0, ol);
@@ -745,6 +755,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 if (k < N && tc == 0 && mine) {
                     T *ivk = tIV_own + k * IV_ROWS;
                     ivk[ta] = v;
+                    ivk[IV_TL + ta] = v - lo;
+                    ivk[IV_TU + ta] = hi - v;
                     ivk[4 + ta] = c.mu0 / (v - lo);
                     ivk[8 + ta] = c.mu0 / (hi - v);
                 }
@@ -752,7 +764,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         }
     };
     T rmaxE = 0, dmaxE = 0;        // sweep E: largest inverse step length (floor tau), largest |d| / box width
-    struct OpsD { T mn[4], y, ri, u, ll, lu, ua, ul; };
+    struct OpsD { T mn[4], y, ri, u, ll, lu, tl, tu, ua, ul; };
     // ================= sweep D: backward homogeneous solve of the corrector: g = dr + B'pi, m0 = L^-1 g, pi_k = Abar'pi - Mbar'm0
     auto sweepD = [&](auto) {
         T Aq0[4], Aq1z[4], Bt[4];
@@ -772,7 +784,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         auto fetch_sc = [&](int kq, OpsD &o) {
             const int k = kq > 0 ? kq : 0;
             const T *ivn = tIV + k * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
         };
         auto fetch_d = [&](int kq, OpsD &o) {           // factors from the HBM scratch (clamped index, see sweep B)
             const int k = kq > 0 ? kq : 0;
@@ -796,10 +808,11 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             }
             T drt;
             {
-                const Pair<T> pr(o.u, o.ll, o.lu, lb_a - o.ul, ub_a - o.ul);
-                const T da = o.ua - o.u;
-                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
-                const T cl = dla * da, cu = -dua * da;
+                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lb_a - o.ul, ub_a - o.ul);
+                const T da = o.ua;                                           // the affine step
+                const T el = da + pr.rl, eu = pr.ru - da;
+                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
+                const T cl = dla * el, cu = dua * eu;
                 drt = tc == 0 ? -(sigmu - cl) * pr.itl + (sigmu - cu) * pr.itu : T(0);
             }
             const T g = mfma44(Bt[2], pit[2], mfma44(Bt[0], pit[0], drt)) + mfma44(Bt[3], pit[3], mfma44(Bt[1], pit[1], T(0)));
@@ -837,8 +850,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 fetch_sc(kl - 2, on2);
                 OpsD ol2;
                 auto scalars = [&](OpsD &o, int k) {
-                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.ua = on.ua; o.ul = on.ul;
-                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
+                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua; o.ul = on.ul;
+                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua; on.ul = on2.ul;
                     fetch_sc(k - 2, on2);
                 };
                 fetch_d_lds(kl - 1, ol);
@@ -872,12 +885,12 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = 0;
         const T one15 = (ta == 3 && tc == 0) ? T(1) : T(0);        // homogeneous coordinate, for the m term only
         T rmx = c.tau, dmx = 0;
-        struct OpsE { T mt[4], z, u, ll, lu, ua, ul, ab[SHARED ? 1 : 12]; };
+        struct OpsE { T mt[4], z, u, ll, lu, tl, tu, ua, ul, ab[SHARED ? 1 : 12]; };
         const int kl = LDSC ? (lstg < N ? lstg : N) : 0;
         const int dslot = tc == 0 ? 16 + ta : 20 + ta;
         auto fetch_sc = [&](int k, OpsE &o) {
             const T *ivn = tIV + k * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
         };
         auto fetch_e = [&](int kq, OpsE &o) {
             const int k = kq < N ? kq : N - 1;
@@ -911,15 +924,17 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             const T ut = mfma44_na(o.z, v, T(0));
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
             {
-                const Pair<T> pr(o.u, o.ll, o.lu, lb_a - o.ul, ub_a - o.ul);
-                const T da = o.ua - o.u;
-                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
-                const T cl = dla * da, cu = -dua * da;
+                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lb_a - o.ul, ub_a - o.ul);
+                const T da = o.ua;
+                const T el = da + pr.rl, eu = pr.ru - da;
+                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
+                const T cl = dla * el, cu = dua * eu;
                 const T d = da + ut;
                 ivk[dslot] = d;
-                const T dl = -o.ll - (cl - sigmu) * pr.itl - pr.kl * d;
-                const T du = -o.lu - (cu - sigmu) * pr.itu + pr.ku * d;
-                rmx = fmax(rmx, fmax(-d * pr.itl, d * pr.itu));
+                const T dtl = d + pr.rl, dtu = pr.ru - d;                   // directions of the two slacks
+                const T dl = -o.ll - (cl - sigmu) * pr.itl - pr.kl * dtl;
+                const T du = -o.lu - (cu - sigmu) * pr.itu - pr.ku * dtu;
+                rmx = fmax(rmx, fmax(-dtl * pr.itl, -dtu * pr.itu));
                 rmx = fmax(rmx, fmax(-dl * fast_rcp(o.ll), -du * fast_rcp(o.lu)));
                 dmx = fmax(dmx, fabs(d) * iw_a);
             }
@@ -937,8 +952,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 fetch_sc(1 < N ? 1 : 0, on2);
                 OpsE ol2;
                 auto scalars = [&](OpsE &o, int k) {
-                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.ua = on.ua; o.ul = on.ul;
-                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.ua = on2.ua; on.ul = on2.ul;
+                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua; o.ul = on.ul;
+                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua; on.ul = on2.ul;
                     fetch_sc(k + 2 < N ? k + 2 : N - 1, on2);
                 };
                 fetch_e_lds(0, ol);
@@ -970,32 +985,36 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         T ms = 0;
         constexpr int CHF = 5;
         for (int k0 = 0; k0 < N; k0 += 4 * CHF) {
-            T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_ua[CHF], f_d[CHF];
+            T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_tl[CHF], f_tu[CHF], f_ua[CHF], f_d[CHF];
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
                 const int kq = k0 + 4 * i + tc;
                 const int k = kq < N ? kq : N - 1;
                 const T *ivn = tIV + k * IV_ROWS;
                 f_ul[i] = ulin(k, ta);
-                f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
+                f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_tl[i] = ivn[IV_TL + ta]; f_tu[i] = ivn[IV_TU + ta];
+                f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
             }
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
                 const int kq = k0 + 4 * i + tc;
                 const bool live = kq < N;
                 // a lane past the horizon repeats stage N - 1 into the spare slots of that stage
                 T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
-                T u = f_u[i], ll = f_ll[i], lu = f_lu[i];
+                T u = f_u[i], ll = f_ll[i], lu = f_lu[i], tl = f_tl[i], tu = f_tu[i];
                 const T lo = lb_a - f_ul[i], hi = ub_a - f_ul[i];
-                const Pair<T> pr(u, ll, lu, lo, hi);
-                const T da = f_ua[i] - u, d = f_d[i];
-                const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
-                const T cl = dla * da, cu = -dua * da;
-                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
-                const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
-                u += alpha * d; ll += alpha * dl; lu += alpha * du;
+                const Pair<T> pr(u, ll, lu, tl, tu, lo, hi);
+                const T da = f_ua[i], d = f_d[i];
+                const T el = da + pr.rl, eu = pr.ru - da;
+                const T dla = -ll - pr.kl * el, dua = -lu - pr.ku * eu;
+                const T cl = dla * el, cu = dua * eu;
+                const T dtl = d + pr.rl, dtu = pr.ru - d;
+                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * dtl;
+                const T du = -lu - (cu - sigmu) * pr.itu - pr.ku * dtu;
+                u += alpha * d; tl += alpha * dtl; tu += alpha * dtu; ll += alpha * dl; lu += alpha * du;
                 ivk[live ? ta : 20 + ta] = u; ivk[live ? 4 + ta : 20 + ta] = ll; ivk[live ? 8 + ta : 20 + ta] = lu;
+                ivk[live ? IV_TL + ta : 20 + ta] = tl; ivk[live ? IV_TU + ta : 20 + ta] = tu;
                 // active-set guess for a later attempt: a bound whose multiplier exceeds its slack
-                ivk[live ? 16 + ta : 20 + ta] = ll > u - lo ? T(-1) : (lu > hi - u ? T(1) : T(0));
-                ms += live ? ll * (u - lo) + lu * (hi - u) : T(0);
+                ivk[live ? 16 + ta : 20 + ta] = ll > tl ? T(-1) : (lu > tu ? T(1) : T(0));
+                ms += live ? ll * tl + lu * tu : T(0);
             }
         }
         msF = ms;
@@ -1019,7 +1038,9 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
                 ivk[live ? ta : 20 + ta] = w_u[i]; ivk[live ? 4 + ta : 20 + ta] = w_l[i]; ivk[live ? 8 + ta : 20 + ta] = w_h[i];
                 const T lo = lb_a - w_ul[i], hi = ub_a - w_ul[i];
-                ms += live ? w_l[i] * (w_u[i] - lo) + w_h[i] * (hi - w_u[i]) : T(0);
+                const T tl = w_u[i] - lo, tu = hi - w_u[i];                  // the slacks of the new iterate start on its inputs
+                ivk[live ? IV_TL + ta : 20 + ta] = tl; ivk[live ? IV_TU + ta : 20 + ta] = tu;
+                ms += live ? w_l[i] * tl + w_h[i] * tu : T(0);
             }
         }
         msF = ms;

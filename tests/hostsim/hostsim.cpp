@@ -86,8 +86,7 @@ extern "C" int hostsim_solve_batch(const nmpc_config *g, int B, const double *x0
                                    double *u0, int32_t *status, double *x_out, double *u_out, int32_t *iters)
 {
     const int shared = (g->flags & NMPC_FLAG_SHARE_COLD_START) ? 1 : 0;
-    if (g->dtype == NMPC_DTYPE_F64) run<double>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);
-    else run<float>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);
+    run<double>(*g, B, x0, yref, yref_e, bcast, x_init, u_init, u0, status, x_out, u_out, iters, shared);     // the arithmetic is FP64 for every dtype
     return 0;
 }
 

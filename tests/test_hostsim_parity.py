@@ -59,15 +59,6 @@ def test_warm_start_and_switches():
     np.testing.assert_allclose(o2["x"], r2["x"], atol=1e-9)
 
 
-def test_fp32_kernel_arithmetic_is_close():
-    cfg = _lib.default_config(dtype=_lib.DTYPE_F32, qp_tol_comp=1e-8, qp_tol_stat=1e-6, qp_iter_max=30)
-    yref, ye = hover_reference(cfg.N, cfg.mass * cfg.gravity / 4.0)
-    x0 = sample_x0(32, 1, **NEAR_HOVER)
-    out = H.solve_batch(cfg, x0, yref, ye)
-    ref = O.solve_batch(O.default_config(qp_gamma=0.0), x0, yref, ye)
-    assert (out["status"] == 0).all() and np.abs(out["u0"] - ref["u0"]).max() < 5e-3
-
-
 @pytest.mark.parametrize("N,cond_N,flags", [(20, 5, 4), (20, 5, 5), (20, 3, 4), (7, 5, 4), (20, 1, 4)])
 def test_partial_condensing_path_matches_oracle(N, cond_N, flags):
     """condensing + IPM on the condensed QP (what acados hands to HPIPM, controller.py:181,184)

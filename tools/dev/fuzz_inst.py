@@ -21,7 +21,6 @@ r0 = O.solve_batch(c, x0, yref, ye, want_traj=True)
 print("oracle ipm   : status", r0["status"], "iters", r0["iters"], "u0", r0["u0"][0])
 print("oracle trajectory: max|x|", np.abs(r0["x"]).max(), "max |omega|", np.abs(r0["x"][0, :, 10:]).max())
 for name, ov, env in (("team default", {}, {}), ("team one kernel", {}, {"NMPC_TEAM_SPLIT": "0"}), ("team plain ipm", dict(qp_polish=0), {}),
-                      ("team row form ipm", dict(qp_polish=0), {"NMPC_TEAM_MFMA": "0"}),
                       ("lane plain ipm", dict(qp_polish=0, flags=over["flags"] & 1), {})):
     for k, v in env.items():
         os.environ[k] = v

@@ -11,7 +11,6 @@ g = runpy.run_path(str(Path(__file__).resolve().parent / "unstable_n120.py"), ru
 O, _lib, NmpcOcpSolver, over = g["O"], g["_lib"], g["NmpcOcpSolver"], g["over"]
 x0, yref, ye = g["x0"][inst:inst + 1], g["yref"], g["ye"]
 for name, ov, env in (("team default", {}, {}), ("team plain ipm", dict(qp_polish=0), {}),
-                      ("team row form ipm", dict(qp_polish=0), {"NMPC_TEAM_MFMA": "0"}),
                       ("lane plain ipm", dict(qp_polish=0, flags=0), {})):
     for k, v in env.items():
         os.environ[k] = v

@@ -18,7 +18,7 @@ for name in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2", "pmc_sq3", "pmc_sq4"
     for r in csv.DictReader(open(files[0])):
         kn = r["Kernel_Name"]
         k = next((t for t in ("k_team_as", "k_team_qp_list", "k_team_qp", "k_team_tail", "k_block_sweep_tail", "k_block_scan_tail", "k_block_sweep",
-                              "k_block_scan", "k_team_ipm_list", "k_team_ipm", "k_team_prepare", "k_ipm", "k_prepare") if t + "<" in kn or t + "(" in kn), None)
+                              "k_block_scan", "k_cond_ipm", "k_ipm", "k_prepare") if t + "<" in kn or t + "(" in kn), None)
         if k:
             agg[(k, r["Counter_Name"])].append(float(r["Counter_Value"]))
             meta[k] = dict(vgpr=int(r["VGPR_Count"]), agpr=int(r["Accum_VGPR_Count"]), sgpr=int(r["SGPR_Count"]),
