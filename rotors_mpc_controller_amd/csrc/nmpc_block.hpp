@@ -94,7 +94,8 @@ __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool 
     o.nan = false;
     auto pivot = [&](T d) -> T {
         const bool pos = d > T(0);
-        ok &= pos; o.nan |= !(d == d);
+        o.nan |= ok && !(d == d);        // (the first failing pivot decides: see riccati_factor_stage)
+        ok &= pos;
         return fast_rcp(pos ? d : T(1));
     };
     o.r0 = pivot(h00);

@@ -28,7 +28,8 @@ class AcadosOcp:
         self.solver_options = SimpleNamespace(
             tf=None, qp_solver=None, hessian_approx=None, integrator_type=None, qp_solver_cond_N=None,
             qp_solver_iter_max=None, collocation_type=None, sim_method_num_stages=4, sim_method_num_steps=1,
-            regularize_method=None, levenberg_marquardt=0.0, nlp_solver_type="SQP_RTI")
+            regularize_method=None, levenberg_marquardt=0.0, nlp_solver_type="SQP_RTI",
+            qp_solver_tol_stat=None, qp_solver_tol_eq=None, qp_solver_tol_ineq=None, qp_solver_tol_comp=None)
         self.cost = SimpleNamespace(cost_type=None, cost_type_e=None, Vx=None, Vu=None, Vx_e=None, W=None,
                                     W_e=None, yref=None, yref_e=None)
         self.constraints = SimpleNamespace(idxbu=None, lbu=None, ubu=None, idxbx_0=None, lbx_0=None, ubx_0=None,
@@ -105,6 +106,16 @@ class AcadosOcpSolver:
                          ubu=np.asarray(con.ubu, float), lm=float(so.levenberg_marquardt),
                          steps=int(so.sim_method_num_steps), iter_max=int(so.qp_solver_iter_max),
                          cond_N=int(so.qp_solver_cond_N), **k)
+        # QP exit.  Default of this stand-in: the oracle's own (exact) solve - what the committed Level-B fixtures were made with.
+        # LEVELB_HPIPM_EXIT=1 (the generator's dry run, tests/test_acados_golden.py): stop the interior point where HPIPM would -
+        # residuals <= the four qp_solver_tol_* (1e-8 each where the OCP leaves them unset, [UPSTREAM U9]) - so that a "default
+        # tolerance" golden set differs from a "tight" one the way acados' will
+        tol = [getattr(so, "qp_solver_tol_" + n, None) for n in ("stat", "eq", "ineq", "comp")]
+        self._hpipm_exit = None
+        if os.environ.get("LEVELB_HPIPM_EXIT") == "1":
+            t = [1e-8 if v is None else float(v) for v in tol]
+            self._hpipm_exit = (max(t[0], t[1], t[2]), t[3])
+        self._last_stats = None
         self._x = np.zeros((N + 1, NX)); self._u = np.zeros((N, NU))
         self._yref = np.tile(np.asarray(cost.yref, float), (N, 1)); self._yref_e = np.asarray(cost.yref_e, float).copy()
         self._x0 = np.asarray(con.lbx_0, float).copy()
@@ -120,6 +131,9 @@ class AcadosOcpSolver:
                                         lm=c["lm"], mass=c["mass"], gravity=c["gravity"], J=c["J"],
                                         rotor_x=c["rotor_x"], rotor_y=c["rotor_y"], rotor_z=c["rotor_z"],
                                         sim_num_steps=c["steps"], qp_iter_max=c["iter_max"], qp_gamma=0.0)
+            if self._hpipm_exit is not None:
+                self._oc.qp_exit_mode = 1
+                self._oc.qp_tol_stat, self._oc.qp_tol_comp = self._hpipm_exit
         elif self.backend == "hip":
             from rotors_mpc_controller_amd import _lib
             from rotors_mpc_controller_amd.solver import NmpcOcpSolver
@@ -151,10 +165,22 @@ class AcadosOcpSolver:
     def get(self, stage, field):
         return (self._x if field == "x" else self._u)[stage].copy()
 
+    def get_stats(self, field):
+        if field == "qp_iter" and self._last_stats is not None:
+            return np.array([self._last_stats.qp_iter])
+        raise NotImplementedError(field)
+
+    def get_residuals(self):
+        """(res_stat, res_eq, res_ineq, res_comp) of the QP the last solve ended on"""
+        st = self._last_stats
+        if st is None:
+            raise NotImplementedError("no solve yet")
+        return np.array([st.res_stat, st.res_eq, 0.0, st.res_comp])
+
     def solve(self):
         if self.backend == "oracle":
             xt = self._x.copy(); xt[0] = self._x0
-            s, xn, un, _ = self._O.sqp_rti(self._oc, self._x0, self._yref, self._yref_e, xt, self._u)
+            s, xn, un, self._last_stats = self._O.sqp_rti(self._oc, self._x0, self._yref, self._yref_e, xt, self._u)
         else:
             out = self._hip.solve_batch(self._x0[None], self._yref, self._yref_e, x_init=self._x[None],
                                         u_init=self._u[None], want_traj=True)

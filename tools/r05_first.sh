@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5, first GPU call: the GPU suite, then the bench rows of tools/bench_table.sh's short list
+set -e
+mkdir -p gpurun_out
+python -c "from rotors_mpc_controller_amd import _lib; print(_lib.load().nmpc_version().decode() if hasattr(_lib.load().nmpc_version(), 'decode') else _lib.load().nmpc_version())" 2>/dev/null || true
+python -m pytest tests -m gpu -x -q > gpurun_out/r05a_gpu_tests.log 2>&1 || { tail -40 gpurun_out/r05a_gpu_tests.log; exit 1; }
+tail -1 gpurun_out/r05a_gpu_tests.log
+for args in "" "--no-share" "--dist aggressive" "--no-polish" "--batch 65536" "--batch 65536 --dtype f32" "--batch 1024 --horizon 600"; do
+  python bench.py --no-cpu-baseline $args > gpurun_out/bench_q.json 2>gpurun_out/bench_q.err || { tail -5 gpurun_out/bench_q.err; exit 1; }
+  python - "$args" <<'PY' | tee -a gpurun_out/r05a_bench_rows.txt
+import json, sys
+d = json.load(open("gpurun_out/bench_q.json"))
+r = d["roofline"]
+print(f"[{sys.argv[1]:32s}] {d['value']/1e6:8.3f} M/s  step {d['ms_per_step']:.4f} ms  kernel {r['kernel_ms']:.4f} (isolated {r['kernel_ms_isolated']:.4f})  "
+      f"ipm {d['ipm_iterations']['mean']:.2f}/{d['ipm_iterations']['max']}  pol {d['active_set_passes']['mean']:.3f}/{d['active_set_passes']['max']}  st {d['status_histogram']}")
+PY
+done
