@@ -202,7 +202,14 @@ def load() -> C.CDLL:
 def library_source_hash() -> str:
     """Hash of the kernel sources the loaded binary was built from (the tail of nmpc_version())."""
     v = load().nmpc_version().decode()
-    return v.rsplit("src ", 1)[1] if "src " in v else "unknown"
+    return v.split("src ", 1)[1].split()[0] if "src " in v else "unknown"
+
+
+def library_codegen() -> str:
+    """Which builds of the kernels the loaded binary runs by default: "flag" (compiled with the two internal LLVM options of csrc/Makefile; they
+    passed the build's codegen gate) or "default" (plain -O3: the gate found something, or hipcc is not the validated version)."""
+    v = load().nmpc_version().decode()
+    return v.split("codegen ", 1)[1].split()[0] if "codegen " in v else "flag"
 
 
 def default_config(**over) -> NmpcConfig:

@@ -180,8 +180,19 @@ extern "C" {
 #ifndef NMPC_SOURCE_HASH
 #define NMPC_SOURCE_HASH "unknown"
 #endif
-// "rotors_nmpc_hip <abi> (gfx950) src <hash of the kernel sources this binary was built from>"
-const char *nmpc_version(void) { return "rotors_nmpc_hip 0.3 (gfx950) src " NMPC_SOURCE_HASH; }
+// NMPC_DEFAULT_NOFLAG (csrc/Makefile, tools/emu/codegen_gate.py): 1 when the build-time scan of the flag builds' assembly found something or hipcc
+// is not the validated version - the default-codegen twins of every kernel then run by default (the NMPC_*_NOFLAG switches of nmpc_create)
+#ifndef NMPC_DEFAULT_NOFLAG
+#define NMPC_DEFAULT_NOFLAG 0
+#endif
+#if NMPC_DEFAULT_NOFLAG
+#define NMPC_CODEGEN_NAME "default"
+#else
+#define NMPC_CODEGEN_NAME "flag"
+#endif
+// "rotors_nmpc_hip <abi> (gfx950) src <hash of the kernel sources this binary was built from> codegen <flag|default>": which builds of the
+// kernels run by default - "flag": the ones compiled with the two internal LLVM options, which passed the build's gate; "default": plain -O3
+const char *nmpc_version(void) { return "rotors_nmpc_hip 0.3 (gfx950) src " NMPC_SOURCE_HASH " codegen " NMPC_CODEGEN_NAME; }
 // sizes of the two public structs in THIS binary: a binding checks them against its own mirror before it trusts either
 // (nmpc_get_stats writes sizeof(nmpc_stats) bytes into the caller's buffer)
 int nmpc_abi_sizes(int *config_bytes, int *stats_bytes)
@@ -350,6 +361,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TEAM_SPLIT")) s->team_split = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_INPLACE")) s->team_inplace = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LIST_GRID")) s->list_grid = std::max(1, std::min(4096, std::atoi(e)));
+    s->as_noflag = s->qp_noflag = s->block_noflag = NMPC_DEFAULT_NOFLAG;        // the build's codegen gate; the three switches below override it either way
     if (const char *e = std::getenv("NMPC_AS_NOFLAG")) s->as_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_QP_NOFLAG")) s->qp_noflag = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_LDS_OVERLAP")) s->lds_overlap = std::atoi(e) != 0;
