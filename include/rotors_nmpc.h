@@ -96,8 +96,8 @@ typedef struct nmpc_config {
      * (then the result is the exact QP solution); otherwise correct the active set (primal-dual
      * active-set step) or fall back to the interior point iteration.                                  */
     int32_t qp_polish;         /* 0 = plain IPM, 1 = on */
-    int32_t qp_polish_passes;  /* active-set corrections per attempt; default 8 (0 = the same) */
-    int32_t qp_polish_budget;  /* no new attempt after this many passes; default 16 (0 = the same) */
+    int32_t qp_polish_passes;  /* active-set corrections per attempt; 0 (default) = the measured policy for the horizon: 8 below N = 160, 16 from there up */
+    int32_t qp_polish_budget;  /* no new attempt after this many passes; 0 (default) = 16: two attempts on short horizons, ONE on long ones */
     double qp_polish_mu;       /* first attempt when mu <= this (>= mu0: before any IPM iteration), then every 100x below */
     int32_t qp_polish_ckpt;    /* leading stages whose Riccati state (P_k, p_k) a corrected active-set pass checkpoints
                                   (the first pass of an attempt keeps at most two): the next pass refactorises only

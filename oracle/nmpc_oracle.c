@@ -112,8 +112,8 @@ void orc_default_config(orc_config *c)
     c->qp_gamma = 0.0;   /* optional safeguard; the HIP kernels do not implement it */
     c->qp_polish = 0;
     c->qp_polish_mu = 1.0;      /* >= mu0: the first attempt is a pure active-set solve from 'all free' */
-    c->qp_polish_passes = 8;   /* = the GPU library's default attempt policy (nmpc_create) */
-    c->qp_polish_budget = 16;
+    c->qp_polish_passes = 0;   /* 0 = the GPU library's default attempt policy for the horizon (orc_polish_policy below) */
+    c->qp_polish_budget = 0;
     c->qp_growth_max = 1e6;    /* ~1e-15 * growth of relative accuracy is lost: 1e-9 is still held */
     c->qp_acc_comp = 1e-8;     /* [UPSTREAM] HPIPM's default res_m_max */
     c->qp_acc_stat = 1e-8;
@@ -806,6 +806,14 @@ static void ipm_true_residuals(const ocpqp *p, const double *dx0, double **u, do
     *res_stat = rs; *res_comp = rc; *res_bnd = rb;
 }
 
+/* attempt policy of the active-set passes where the configuration leaves it at 0: the library's rule (csrc/nmpc_consts.hpp,
+ * resolve_polish_policy, which has the measurement) - 8 passes per attempt and 16 in total below N = 160, ONE attempt of 16 from there up */
+static void orc_polish_policy(const orc_config *c, int N, int *passes, int *budget)
+{
+    *passes = c->qp_polish_passes > 0 ? c->qp_polish_passes : (N >= 160 ? 16 : 8);
+    *budget = c->qp_polish_budget > 0 ? c->qp_polish_budget : (N >= 160 ? (*passes > 16 ? *passes : 16) : 2 * *passes);
+}
+
 /* standard (cold) start point of the interior-point iteration: inputs pushed inside the box, multipliers on the central path of mu0 */
 static void ipm_cold_point(const orc_config *c, const ocpqp *p, double **u, double **ll, double **lu, double **tlo, double **tup)
 {
@@ -864,6 +872,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     int polished = 0, npolish = 0, untrusted = 0;
     int warm_derived = 0;   /* the iterate descends from a warm start (an exhausted attempt's last pass), not from the cold point */
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
+    int pol_passes, pol_budget;
+    orc_polish_policy(c, c->N, &pol_passes, &pol_budget);
     /* [UPSTREAM U9] exit of HPIPM at its DEFAULT tolerances (qp_exit_mode = 1; acados leaves res_g/b/d/m_max at 1e-8 and
      * controller.py:179-190 sets none): all four TRUE residuals of the iterate - stationarity, dynamics (0 here: the states
      * are implied), bounds (|u - lo - t|), complementarity (max lam t, as HPIPM's res_m with mu = 0) - at most qp_tol_stat /
@@ -881,15 +891,15 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
             ipm_true_residuals(p, dx0, u, ll, lu, tlo, tup, NULL, &rs, &rc, &rb);
             if (rs <= c->qp_tol_stat && rc <= c->qp_tol_comp && rb <= c->qp_tol_stat) break;
         } else if (mu <= c->qp_tol_comp && rho <= c->qp_tol_stat && (it == 0 || !(c->qp_tol_step > 0.0) || step_last <= c->qp_tol_step)) break;
-        if (c->qp_polish && mu <= pol_mu && npolish < c->qp_polish_budget) {
+        if (c->qp_polish && mu <= pol_mu && npolish < pol_budget) {
             int trip = 0, warm = 0;
             /* the warm start is for the iteration BETWEEN two attempts: an attempt that uses up the budget leaves the iterate alone */
-            const int last_attempt = npolish + c->qp_polish_passes >= c->qp_polish_budget;
-            if (ocpqp_polish(p, dx0, &f, u, ll, lu, tlo, tup, x, c->qp_polish_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip,
+            const int last_attempt = npolish + pol_passes >= pol_budget;
+            if (ocpqp_polish(p, dx0, &f, u, ll, lu, tlo, tup, x, pol_passes, &npolish, c->qp_growth_max, &gbase, &growth, &trip,
                              (c->qp_warm_start && !last_attempt) ? &warm : NULL)) {
                 polished = 1; mu = 0.0; rho = 0.0; break;
             }
-            if (trip) { untrusted = 1; npolish = c->qp_polish_budget; }     /* the same pins would fail the same way: no further attempt */
+            if (trip) { untrusted = 1; npolish = pol_budget; }     /* the same pins would fail the same way: no further attempt */
             pol_mu *= 1e-2;
             if (warm) {      /* the iterate was replaced: its duality measure, and nothing known about its stationarity */
                 mu = 0.0;
@@ -901,7 +911,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 warm_derived = 1;
                 /* (pol_mu is not touched: the warm point's mu ~ 1e-3 is already below the threshold of the next attempt, which
                  * therefore follows after ONE interior-point iteration - the iteration that re-derives the active-set guess) */
-            } else if (warm_derived && npolish >= c->qp_polish_budget) {
+            } else if (warm_derived && npolish >= pol_budget) {
                 /* no attempt is left and the iterate in hand descends from a warm start - off the central path, a poor place to
                  * converge from (42 iterations and 1e-6 of accuracy on fuzz draw 353, against 15 and 2e-8): the interior point
                  * finishes the QP from its standard cold point                                                                */

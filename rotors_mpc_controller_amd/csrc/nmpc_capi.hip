@@ -242,8 +242,8 @@ void nmpc_default_config(nmpc_config *c)
     c->max_batch = 4096;
     c->flags = NMPC_FLAG_SHARE_COLD_START | NMPC_FLAG_TEAM_MAPPING;
     c->qp_polish = 1;
-    c->qp_polish_passes = 8;   // the measured default (nmpc_create): 8 passes per attempt, 16 in total; 0 means the same
-    c->qp_polish_budget = 16;
+    c->qp_polish_passes = 0;   // 0 = the measured policy for the horizon (resolve_polish_policy, nmpc_consts.hpp): 8 per attempt / 16 in total
+    c->qp_polish_budget = 0;   // below N = 160, one attempt of 16 from there up
     c->qp_polish_mu = 1.0;
     c->qp_polish_ckpt = 12;
     c->qp_maxiter_status = 0;
@@ -348,8 +348,8 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     // (measured on MI355X, B = 4096: aggressive set 6.6 M solves/s with 5 / 8 - 31 instances in the second launch - against
     // 18.7 M with 8 / 16, none; N = 250 near-hover 14.9 ms against 3.5 ms; N = 600 43.3 ms against 39.6 ms; more than 8 / 16
     // changed nothing or lost: N = 600 12 / 24 42.8 ms).  The near-hover N = 20 set needs 3 passes at most either way.
-    if (s->cfg.qp_polish_passes <= 0) s->cfg.qp_polish_passes = 8;
-    if (s->cfg.qp_polish_budget <= 0) s->cfg.qp_polish_budget = 16;
+    // ... from N = 160 up: ONE attempt of 16 passes (nmpc_consts.hpp: resolve_polish_policy has the measurement)
+    resolve_polish_policy(s->cfg.N, s->cfg.qp_polish_passes, s->cfg.qp_polish_budget);
     if (cfg->dtype == NMPC_DTYPE_F32) s->cfg.dtype = NMPC_DTYPE_F32IO;     // one FP32-buffer path
     s->esz = cfg->dtype == NMPC_DTYPE_F64 ? 8 : 4;
     s->wsz = 8;                                                             // workspace and arithmetic are always double
@@ -393,7 +393,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         // schedule in which the second attempt is the last (the tail never leaves a second warm start behind).
         const nmpc_config &g = s->cfg;
         const bool can = (g.flags & NMPC_FLAG_TEAM_MAPPING) && !(g.flags & NMPC_FLAG_CONDENSED_QP) && g.qp_polish &&
-                         g.qp_warm_start && g.qp_polish_budget > g.qp_polish_passes && g.qp_polish_budget <= 2 * g.qp_polish_passes &&
+                         g.qp_warm_start && g.qp_polish_budget >= g.qp_polish_passes && g.qp_polish_budget <= 2 * g.qp_polish_passes &&
                          g.sim_num_steps <= AS_MAX_STEPS && s->team_split && g.N >= 8;
         const bool want = s->block_tail < 0 ? g.N >= 160 : s->block_tail != 0;
         if (can && want) {
@@ -652,9 +652,11 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         if (step(0, false)) return NMPC_EHIP;
         for (int p = cap; p < s->cfg.qp_polish_passes; p++)          // the rest of the first attempt
             if (step(2, true)) return NMPC_EHIP;
-        if (step(1, true)) return NMPC_EHIP;                         // one interior-point iteration from the warm start
-        for (int p = 0; p < s->cfg.qp_polish_budget - s->cfg.qp_polish_passes; p++)   // the second attempt
-            if (step(2, true)) return NMPC_EHIP;
+        if (s->cfg.qp_polish_budget > s->cfg.qp_polish_passes) {     // (a one-attempt policy - long horizons by default - ends here: what is left goes to the fallback list)
+            if (step(1, true)) return NMPC_EHIP;                     // one interior-point iteration from the warm start
+            for (int p = 0; p < s->cfg.qp_polish_budget - s->cfg.qp_polish_passes; p++)   // the second attempt
+                if (step(2, true)) return NMPC_EHIP;
+        }
         AsLaunch ql = al;
         qp_lds(s, c.shared != 0, ql);
         ql.kind = 2; ql.nlist = nlist; ql.tpw = 4; ql.occ = 1; ql.wl = wl2;

@@ -9,6 +9,19 @@
 
 namespace nmpc {
 
+// Attempt policy of the active-set passes where nmpc_config leaves it at 0 (the default): 8 passes per attempt, 16 in total below N = 160;
+// from N = 160 up ONE attempt of 16 passes.  Why the long horizon differs (round 5, measured on config 5: N = 600, B = 1024, near hover):
+// an interior-point iteration between two attempts is three sequential 600-stage solves (0.9 ms of a 7.3 ms solve) and re-derives the
+// active set the passes were converging to anyway - with one attempt of 16 every instance of the sample is accepted without one (14 passes
+// at most instead of 8 + 1 iteration + 5), and the commands are the same bits (an accepted pass is the exact solution of the same pinned
+// problem).  On short horizons the split schedule stays: there the iteration is cheap and caps what a wave's slowest team costs its mates.
+// The oracle applies the same rule (oracle/nmpc_oracle.c: orc_polish_policy).
+inline void resolve_polish_policy(int N, int &passes, int &budget)
+{
+    if (passes <= 0) passes = N >= 160 ? 16 : 8;
+    if (budget <= 0) budget = N >= 160 ? (passes > 16 ? passes : 16) : 2 * passes;
+}
+
 template <class T>
 void fill_consts(const nmpc_config &g, Consts<T> &c)
 {
@@ -51,6 +64,7 @@ void fill_consts(const nmpc_config &g, Consts<T> &c)
     c.polish = g.qp_polish;
     c.polish_passes = g.qp_polish_passes;
     c.polish_budget = g.qp_polish_budget;
+    resolve_polish_policy(g.N, c.polish_passes, c.polish_budget);
     c.polish_ckpt = g.qp_polish_ckpt < 0 ? 0 : (g.qp_polish_ckpt > g.N - 1 ? g.N - 1 : g.qp_polish_ckpt);
     c.polish_mu = (T)g.qp_polish_mu;
     c.kkt_tol = sizeof(T) == 8 ? (T)1e-9 : (T)1e-5;   // the oracle uses 1e-9; FP32 gradients carry ~1e-6 noise

@@ -159,4 +159,4 @@ def test_binding_mirrors_the_structs_of_the_loaded_library():
     from source_hash import source_hash
     assert _lib.library_source_hash() == source_hash()
     cfg = _lib.default_config()
-    assert cfg.qp_polish_passes == 8 and cfg.qp_polish_budget == 16 and cfg.qp_growth_max == 1e6 and cfg.qp_maxiter_status == 0
+    assert cfg.qp_polish_passes == 0 and cfg.qp_polish_budget == 0 and cfg.qp_growth_max == 1e6 and cfg.qp_maxiter_status == 0      # (0: the policy for the horizon)
