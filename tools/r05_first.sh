@@ -3,7 +3,7 @@
 set -e
 mkdir -p gpurun_out
 python -c "from rotors_mpc_controller_amd import _lib; print(_lib.load().nmpc_version().decode() if hasattr(_lib.load().nmpc_version(), 'decode') else _lib.load().nmpc_version())" 2>/dev/null || true
-python -m pytest tests -m gpu -x -q > gpurun_out/r05a_gpu_tests.log 2>&1 || { tail -40 gpurun_out/r05a_gpu_tests.log; exit 1; }
+python -m pytest tests -m gpu -q > gpurun_out/r05a_gpu_tests.log 2>&1 || { tail -40 gpurun_out/r05a_gpu_tests.log; exit 1; }
 tail -1 gpurun_out/r05a_gpu_tests.log
 for args in "" "--no-share" "--dist aggressive" "--no-polish" "--batch 65536" "--batch 65536 --dtype f32" "--batch 1024 --horizon 600"; do
   python bench.py --no-cpu-baseline $args > gpurun_out/bench_q.json 2>gpurun_out/bench_q.err || { tail -5 gpurun_out/bench_q.err; exit 1; }
