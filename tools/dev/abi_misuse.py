@@ -11,6 +11,7 @@ import torch
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 
 lib = _lib.load()
 cfg = _lib.default_config(max_batch=8)

@@ -2,6 +2,7 @@
 import os, sys, subprocess, json
 import numpy as np
 sys.path.insert(0, '.')
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 N = int(sys.argv[1]); B = int(sys.argv[2]); dist = sys.argv[3] if len(sys.argv) > 3 else "near"
 if len(sys.argv) > 4 and sys.argv[4] == "child":
     from rotors_mpc_controller_amd import _lib

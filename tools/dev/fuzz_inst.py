@@ -4,6 +4,7 @@ import sys, os
 from pathlib import Path
 import numpy as np
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 import runpy
 seed, inst = int(sys.argv[1]), int(sys.argv[2])
 sys.argv = [sys.argv[0], str(seed)]

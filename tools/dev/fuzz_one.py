@@ -7,6 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from oracle import oracle as O
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 from tests.fuzz_draws import draw, oracle_config
 seed = int(sys.argv[1])
 over, x0, yref, ye, hov, di, rng = draw(seed)

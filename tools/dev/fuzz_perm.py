@@ -9,6 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
 n_draws = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -11,6 +11,7 @@ from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.rollout import ClosedLoopRollout
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 from tests.oracle_solver import OracleOcpSolver
 n_draws = int(sys.argv[1]) if len(sys.argv) > 1 else 20
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0

@@ -4,6 +4,7 @@ from oracle import oracle as O
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 N = int(sys.argv[1]); B = 64
 s = NmpcOcpSolver(_lib.default_config(N=N, max_batch=B, qp_polish=0))
 yref, ye = hover_reference(N, 0.68 * 9.81 / 4)

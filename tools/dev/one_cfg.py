@@ -8,6 +8,7 @@ from oracle import oracle as O
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, hover_reference, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 steps, share, polish, traj, B, seed = [int(a) for a in sys.argv[1:7]]
 s = NmpcOcpSolver(_lib.default_config(N=20, max_batch=B, sim_num_steps=steps, qp_polish=polish, flags=_lib.FLAG_TEAM_MAPPING | share))
 yref, ye = hover_reference(20, 0.68 * 9.81 / 4)

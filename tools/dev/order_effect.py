@@ -7,6 +7,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 B, N = 4096, 20
 dev = torch.device("cuda", 0)
 x0 = torch.from_numpy(sample_x0(B, 0, **NEAR_HOVER)).to(dev)

@@ -9,6 +9,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from rotors_mpc_controller_amd import _lib  # noqa: E402
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver  # noqa: E402
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0  # noqa: E402
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 600
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 1024

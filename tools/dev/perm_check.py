@@ -6,6 +6,7 @@ import torch
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 N, B = int(sys.argv[1]), int(sys.argv[2])
 s = NmpcOcpSolver(_lib.default_config(N=N, max_batch=B))
 yref, ye = hover_reference(N, 0.68 * 9.81 / 4)

@@ -4,6 +4,7 @@ from oracle import oracle as O
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import sample_x0, NEAR_HOVER, AGGRESSIVE, hover_reference
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
 yref, ye = hover_reference(20, 0.68*9.81/4)
 for share in (1, 0):

@@ -1,0 +1,17 @@
+#!/bin/bash
+# round 5: the three parity campaigns of rounds 3-4 re-run on the build that carries its slacks (5160 draws: seeds 0-459, 1000-2199, 3000-6499),
+# in chunks that fit one GPU call each:  gpurun -- bash tools/dev/r05_fuzz.sh <a|b|c|d>
+# plus (d) a campaign on seeds no build has seen (7000-7999) and the short fuzzers of the other kinds
+mkdir -p gpurun_out
+case "$1" in
+  a) timeout -k 10 500 python tools/dev/fuzz_parity.py 460 0 > gpurun_out/r05_fuzz_parity_draws_0_459.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_0_459.txt
+     timeout -k 10 560 python tools/dev/fuzz_parity.py 1200 1000 > gpurun_out/r05_fuzz_parity_draws_1000_2199.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_1000_2199.txt ;;
+  b) timeout -k 10 1060 python tools/dev/fuzz_parity.py 1750 3000 > gpurun_out/r05_fuzz_parity_draws_3000_4749.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_3000_4749.txt ;;
+  c) timeout -k 10 1060 python tools/dev/fuzz_parity.py 1750 4750 > gpurun_out/r05_fuzz_parity_draws_4750_6499.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_4750_6499.txt ;;
+  d) timeout -k 10 500 python tools/dev/fuzz_parity.py 1000 7000 > gpurun_out/r05_fuzz_parity_draws_7000_7999.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_7000_7999.txt
+     timeout -k 10 200 python tools/dev/fuzz_perm.py 200 800 > gpurun_out/r05_fuzz_permutation_draws_800_999.txt 2>&1; tail -1 gpurun_out/r05_fuzz_permutation_draws_800_999.txt
+     timeout -k 10 150 python tools/dev/fuzz_f32io.py 150 500 > gpurun_out/r05_fuzz_f32io_draws_500_649.txt 2>&1; tail -1 gpurun_out/r05_fuzz_f32io_draws_500_649.txt
+     timeout -k 10 120 python tools/dev/fuzz_nan.py 150 500 > gpurun_out/r05_fuzz_nan_isolation_draws_500_649.txt 2>&1; tail -1 gpurun_out/r05_fuzz_nan_isolation_draws_500_649.txt
+     timeout -k 10 100 python tools/dev/fuzz_parity.py 120 8000 --lane > gpurun_out/r05_fuzz_lane_kernel_draws_8000_8119.txt 2>&1; tail -1 gpurun_out/r05_fuzz_lane_kernel_draws_8000_8119.txt
+     timeout -k 10 100 python tools/dev/fuzz_parity.py 60 8200 --cond > gpurun_out/r05_fuzz_condensed_kernel_draws_8200_8259.txt 2>&1; tail -1 gpurun_out/r05_fuzz_condensed_kernel_draws_8200_8259.txt ;;
+esac

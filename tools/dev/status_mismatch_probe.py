@@ -11,6 +11,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent.parent))
 from oracle import oracle as O  # noqa: E402
 from rotors_mpc_controller_amd import _lib  # noqa: E402
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver  # noqa: E402
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 from tests.fuzz_draws import draw, oracle_config  # noqa: E402
 
 for seed in (int(a) for a in sys.argv[1:]):

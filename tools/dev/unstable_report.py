@@ -8,6 +8,7 @@ from oracle import oracle as O
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
 from rotors_mpc_controller_amd.synthetic import sample_x0
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 from tests.fuzz_draws import WILD, oracle_config
 GM = float(sys.argv[1]) if len(sys.argv) > 1 else 1e6
 for N in (31, 120):

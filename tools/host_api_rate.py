@@ -13,6 +13,7 @@ import torch  # noqa: E402,F401
 from rotors_mpc_controller_amd import _lib  # noqa: E402
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver  # noqa: E402
 from rotors_mpc_controller_amd.synthetic import NEAR_HOVER, hover_reference, sample_x0  # noqa: E402
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 
 for B in (4096, 65536):
     s = NmpcOcpSolver(_lib.default_config(max_batch=B))

@@ -7,6 +7,7 @@ if mode != 'notorch':
     if mode == 'init': torch.zeros(1, device='cuda'); print('init done')
 from rotors_mpc_controller_amd import _lib
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 cfg = _lib.default_config(max_batch=64)
 try:
     s = NmpcOcpSolver(cfg); print(mode, 'create OK')

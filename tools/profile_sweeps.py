@@ -22,6 +22,7 @@ import torch  # noqa: E402
 from rotors_mpc_controller_amd import _lib  # noqa: E402
 from rotors_mpc_controller_amd.solver import NmpcOcpSolver  # noqa: E402
 from rotors_mpc_controller_amd.synthetic import AGGRESSIVE, NEAR_HOVER, hover_reference, sample_x0  # noqa: E402
+import tools.dev._banner  # noqa: F401,E402  (first line of output: which binary runs)
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--batch", type=int, default=4096)
