@@ -385,11 +385,13 @@ static void ocpqp_free(ocpqp *p)
 }
 
 /* in-place lower Cholesky of an m*m row-major SPD matrix; returns 0 ok, 1 not SPD */
+/* returns 0 ok | 1 a pivot is not positive | 2 the first pivot to fail is a NaN (NaN data) */
 static int chol_lower(double *M, int m)
 {
     for (int j = 0; j < m; j++) {
         double d = M[j * m + j];
         for (int k = 0; k < j; k++) d -= M[j * m + k] * M[j * m + k];
+        if (!(d == d)) return 2;
         if (!(d > 0.0)) return 1;
         d = sqrt(d);
         M[j * m + j] = d;
@@ -432,7 +434,8 @@ typedef struct {
 
 /* Backward Riccati sweep.  factor != 0: build L,M from D (= R + diag(sig)) and the data;
  * always: vector recursion with gradient rhat, offsets bb (NULL = 0), state gradient qq
- * (NULL = 0), terminal qN (NULL = 0).  Returns 0 ok, 1 factorisation failure.           */
+ * (NULL = 0), terminal qN (NULL = 0).  Returns 0 ok, 1 factorisation failure (a pivot that is not positive), 2 the first pivot to
+ * fail is a NaN: NaN data (the kernels make the same distinction: nmpc_stage.hpp pivot()).  */
 static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int homogeneous,
                             int factor, ricc_fact *f, double *gmax)
 {
@@ -494,7 +497,7 @@ static int riccati_backward(const ocpqp *p, double **sig, double **rhat, int hom
                     for (int l = 0; l < NX; l++) s += A[l * NX + i] * PA[l * NX + j];
                     Hxx[i * NX + j] = s;
                 }
-            if (chol_lower(L, m)) { orc_free(PB); orc_free(gu); return 1; }
+            { const int cf = chol_lower(L, m); if (cf) { orc_free(PB); orc_free(gu); return cf; } }
             trsm_lower(L, m, M, NX);
             /* P_k = Hxx - M'M, symmetrised */
             for (int i = 0; i < NX; i++)
@@ -960,7 +963,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                 /* this factorisation cannot be used: the QP ends at the current iterate - solved if that is within the
                  * acceptable tolerances, a QP failure otherwise */
                 if (trip) untrusted = 1;
-                status = (mu <= c->qp_acc_comp && rho <= c->qp_acc_stat) ? 0 : (trip ? 4 : 3);
+                status = (mu <= c->qp_acc_comp && rho <= c->qp_acc_stat) ? 0 : (trip ? 4 : (fail == 2 ? 1 : 3));
                 break;
             }
         }
@@ -1233,8 +1236,12 @@ int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
     int bad = 0;
     for (int i = 0; i < (N + 1) * NX; i++) if (!(dx[i] == dx[i]) || fabs(dx[i]) > 1e300) bad = 1;
     for (int i = 0; i < N * NU; i++) if (!(du[i] == du[i]) || fabs(du[i]) > 1e300) bad = 1;
-    if (bad || qps == 1) status = 1;           /* ACADOS_NAN_DETECTED */
+    /* (a QP that failed is a QP failure whatever the step it left holds - acados returns ACADOS_QP_FAILURE before it looks at the step;
+     * NaN data shows as a NaN pivot inside the QP: qps == 1.  Until round 5 a NaN anywhere in the discarded step of a failed QP read as
+     * status 1: seed 431 of the fuzz, a warm start at |x| 8e5, came back 1 here and 4 from the kernels) */
+    if (qps == 1) status = 1;                  /* ACADOS_NAN_DETECTED */
     else if (qps == 3 || qps == 4) status = 4; /* QP min step / factorisation / untrusted factorisation -> QP_FAILURE */
+    else if (bad) status = 1;
     else if (qps == 2) status = c->qp_maxiter_status ? 2 : 0;   /* QP max-iter: tolerated in RTI or reported (U10 switch) */
     else status = 0;
     if (status == 0) {
