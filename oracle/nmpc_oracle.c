@@ -21,10 +21,6 @@
 
 #define ORC_WARM_DELTA 1e-3   /* warm start of the interior point from a failed attempt: distance from the bounds / box width */
 #define ORC_WARM_MU 1e-3      /* ... and the central-path value that floors its multipliers */
-/* bound residuals u - lo - t_l, hi - u - t_u of the interior point's iterate enter its Newton system (HPIPM's res_d); 0: left out */
-#ifndef ORC_BOUND_RESIDUAL
-#define ORC_BOUND_RESIDUAL 1
-#endif
 #define NX ORC_NX
 #define NU ORC_NU
 #define NY ORC_NY
@@ -121,6 +117,7 @@ void orc_default_config(orc_config *c)
     c->qp_maxiter_status = 0;
     c->qp_warm_start = 1;
     c->qp_exit_mode = 0;
+    c->qp_bound_res = 0;
 }
 
 /* ------------------------------------------------------------------------------------ */
@@ -743,8 +740,8 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
  * OCP-QP, Riccati factorisation of the KKT system, cold-started every call (U9).
  * The slacks of the input bounds are ITERATES of their own, as in HPIPM (d_ocp_qp_ipm: v, pi, lam, t): t_l, t_u start at
  * u - lo, hi - u and are updated t <- t + alpha dt with dt from the linearised bound equations, dt_l = du + (u - lo - t_l),
- * dt_u = -du + (hi - u - t_u); the bound residuals in the brackets (HPIPM's res_d) are zero to rounding and enter the
- * right-hand side of the Newton system like any other residual.  A slack is never formed as the difference u - lo of two
+ * dt_u = -du + (hi - u - t_u); the bound residuals in the brackets (HPIPM's res_d) are zero to rounding - qp_bound_res = 1 feeds
+ * them into the right-hand side of the Newton system as HPIPM does, the default leaves them out (measured: no difference).  A slack is never formed as the difference u - lo of two
  * numbers of magnitude 1-10 again: at mu <= 1e-11 with a multiplier in the thousands the central path puts it at 1e-14,
  * below the resolution of that difference (round 4: 13 fuzz instances ended NaN here because u - lo rounded to 0).
  * States are implied by the (affine) dynamics, so the residuals that matter are stationarity
@@ -930,9 +927,11 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
          * (b + B u_it), input gradient r + R u_it, state gradient q + S'u_it, input Hessian R + sig - states stay absolute, inputs become deltas.  The
          * target form of rounds 1-4 (solve for ua, then d = ua - u) loses everything of d below ulp(u), and a slack carried to
          * 1e-14 needs its direction to that accuracy: the step of a nearly active input is d ~ -t, formed here as
-         * gradient / (R + sig) without a cancellation.  Bound residuals of the iterate (HPIPM's res_d; the start is feasible
-         * and t follows u exactly in exact arithmetic, so they hold rounding of size ulp(u)) stay fixed over the iteration and
-         * enter the affine right-hand side, so that the step restores u - lo = t_l, hi - u = t_u as far as u can resolve it */
+         * gradient / (R + sig) without a cancellation.  Bound residuals of the iterate (HPIPM's res_d): with qp_bound_res = 1
+         * they stay fixed over the iteration and enter the affine right-hand side, so that the step restores u - lo = t_l,
+         * hi - u = t_u as far as u can resolve it; the start is feasible and t follows u exactly in exact arithmetic, so they hold
+         * rounding of size ulp(u) and the default (0, what the kernels do) leaves them out - tests/test_oracle_qp.py shows
+         * iteration counts and commands unchanged either way */
         for (int k = 0; k < N; k++) {
             const int m = p->nu[k];
             for (int i = 0; i < NX; i++) {
@@ -945,8 +944,8 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
             }
             for (int i = 0; i < m; i++) {
                 const double tl = tlo[k][i], tu = tup[k][i];
-                rbl[k][i] = ORC_BOUND_RESIDUAL ? (u[k][i] - p->lo[k][i]) - tl : 0.0;
-                rbu[k][i] = ORC_BOUND_RESIDUAL ? (p->hi[k][i] - u[k][i]) - tu : 0.0;
+                rbl[k][i] = c->qp_bound_res ? (u[k][i] - p->lo[k][i]) - tl : 0.0;
+                rbu[k][i] = c->qp_bound_res ? (p->hi[k][i] - u[k][i]) - tu : 0.0;
                 sig[k][i] = ll[k][i] / tl + lu[k][i] / tu;
                 double s2 = p->r[k][i];
                 for (int j = 0; j < m; j++) s2 += p->R[k][i * m + j] * u[k][j];

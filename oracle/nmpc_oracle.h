@@ -79,6 +79,9 @@ typedef struct orc_config {
                                residuals of the iterate in the infinity norm, stationarity and bound equations <= qp_tol_stat, max
                                complementarity product <= qp_tol_comp (HPIPM / acados default 1e-8 each; controller.py:179-190 sets
                                none).  Mode 1 exists to predict acados' accuracy floor on this OCP (tests/test_acados_floor.py)   */
+    int qp_bound_res;       /* 1: the residuals of the bound equations, u - lo - t_l and hi - u - t_u (HPIPM's res_d), are fed back into the
+                               Newton system of every interior-point iteration.  0 (default, what the kernels do): left out - the start is
+                               feasible, t follows u exactly in exact arithmetic, what the residuals hold is rounding of size ulp(u)      */
 } orc_config;
 
 typedef struct orc_stats {

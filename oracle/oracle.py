@@ -31,7 +31,7 @@ class OrcConfig(C.Structure):
         ("qp_thr0_rel", C.c_double), ("qp_gamma", C.c_double),
         ("qp_polish", C.c_int), ("qp_polish_mu", C.c_double), ("qp_polish_passes", C.c_int), ("qp_polish_budget", C.c_int),
         ("qp_growth_max", C.c_double), ("qp_acc_comp", C.c_double), ("qp_acc_stat", C.c_double), ("qp_tol_step", C.c_double),
-        ("qp_maxiter_status", C.c_int), ("qp_warm_start", C.c_int), ("qp_exit_mode", C.c_int),
+        ("qp_maxiter_status", C.c_int), ("qp_warm_start", C.c_int), ("qp_exit_mode", C.c_int), ("qp_bound_res", C.c_int),
     ]
 
 

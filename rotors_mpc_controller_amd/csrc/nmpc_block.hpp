@@ -190,19 +190,23 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     // operands of a stage - its 11 stored tiles and 8 to 11 scalars - arrive TWO stages ahead in two alternating register sets: a block
     // sweep runs on a few waves (the tail's lists are short), its stage is shorter than an HBM round trip, and one stage ahead left part of
     // every load exposed (2.5 us per stage against 1.45 us for the same stage in the solver's sweep, whose tiles sit in LDS)
-    struct StOps { T pfs[12], yx, yu, xl, ul, pc, pca, ulc, u, ll, lu, tl, tu, uc; };
+    struct StOps { T pfs[12], pft[4], yx, yu, xl, ul, pc, pca, ulc, u, ll, lu, tl, tu; };
     auto fetch_ops = [&](int kq, StOps &o) {
         const int kc = kq > s ? kq : s;                     // clamped, not skipped (see sweepB of nmpc_team_as.hpp)
         const int k = shared ? 0 : kc;
         const T *a = tAB + (size_t)k * TAB_ROWS + r;
         NMPC_UNROLL for (int t = 0; t < 12; t++) o.pfs[t] = (t == 9) ? T(0) : a[t * 16];      // tile (3,0) is zero and never stored
+        {   // the four input tiles once more, transposed (the operand of b += B v: nmpc_stage.hpp)
+            const T *at = tAB + (size_t)k * TAB_ROWS + (tc * 4 + ta);
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) o.pft[kt] = at[(kt * 3 + 2) * 16];
+        }
         o.yx = (T)yr[(size_t)kc * NY + rr]; o.yu = (T)yr[(size_t)kc * NY + NX + ta];
         o.xl = xlin(kc); o.ul = ulin(kc, ta);
         o.pc = tIV[kc * IV_ROWS + 16 + j]; o.pca = tIV[kc * IV_ROWS + 16 + ta]; o.ulc = ulin(kc, j);
-        o.u = 0; o.ll = 0; o.lu = 0; o.tl = 1; o.tu = 1; o.uc = 0;      // the iterate of input a, the input of component c (interior-point iteration)
+        o.u = 0; o.ll = 0; o.lu = 0; o.tl = 1; o.tu = 1;                 // the iterate of input a (interior-point iteration)
         if (TAIL) {
             const T *ivn = tIV + kc * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.uc = ivn[j];
+            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta];
         }
     };
 
@@ -249,11 +253,11 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
     T gm = 0;
     bool nanp = false;
     auto stage = [&](int k, StOps &o) {
-        T Aq0[4], Aq1b[4], Bt[4];
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = o.pfs[kt * 3]; Aq1b[kt] = o.pfs[kt * 3 + 1]; Bt[kt] = o.pfs[kt * 3 + 2]; }
+        T Aq0[4], Aq1b[4], Bt[4], BtT[4];
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = o.pfs[kt * 3]; Aq1b[kt] = o.pfs[kt * 3 + 1]; Bt[kt] = o.pfs[kt * 3 + 2]; BtT[kt] = o.pft[kt]; }
         StageIn sin;
         sin.ul = o.ul; sin.pc = o.pc; sin.pca = o.pca; sin.ulc = o.ulc; sin.u_it = o.u; sin.ll_it = o.ll; sin.lu_it = o.lu;
-        sin.tl_it = o.tl; sin.tu_it = o.tu; sin.u_itc = o.uc;
+        sin.tl_it = o.tl; sin.tu_it = o.tu;
         T rk = Wr_a * (sin.ul - o.yu);
         sin.q_r = Wq_r * (o.xl - o.yx);
         asm volatile("" : "+v"(rk));
@@ -273,7 +277,7 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
                     if (TAIL) tLM[(size_t)k * TLM_ROWS + TLM_RINV + ta + (tc == 0 ? 0 : 4)] = f.ra;        // 1 / d_a for the corrector's solves
                 }
             });
-        riccati_factor_stage<true, TAIL, false, !AGG>(SL, sh, sHg, r, Aq0, Aq1b, Bt, sin, !ipm, ipm, Pt, gm, ok, nanp, so, sink);
+        riccati_factor_stage<true, TAIL, false, !AGG>(SL, sh, sHg, r, Aq0, Aq1b, Bt, BtT, sin, !ipm, ipm, Pt, gm, ok, nanp, so, sink);
         const T Y = so.Y, ra = so.ra, mask_a = so.mask_a;
         const T (&Aq1)[4] = so.Aq1;
         const T (&M)[4] = so.M;

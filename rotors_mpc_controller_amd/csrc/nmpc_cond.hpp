@@ -325,8 +325,7 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         PairC p;
         p.u = CWV(o + cw.oU + i); p.ll = CWV(o + cw.oLL + i); p.lu = CWV(o + cw.oLU + i);
         p.tl = CWV(o + cw.oTL + i); p.tu = CWV(o + cw.oTU + i);
-        p.rl = (p.u - CWV(o + cw.oLO + i)) - p.tl;
-        p.ru = (CWV(o + cw.oHI + i) - p.u) - p.tu;
+        p.rl = 0; p.ru = 0;         // (bound residuals: zero in exact arithmetic, left out as in the tile kernels - nmpc_team.hpp, Pair)
         return p;
     };
     for (;;) {

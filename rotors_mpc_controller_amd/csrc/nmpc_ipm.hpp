@@ -125,15 +125,17 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
     T mu = c.mu0, rho = T(1), alpha = 0, sigmu = 0;
     int it = 0, status = 0;
     bool pending = false;
-    // one bound pair of the iterate as a sweep sees it (oracle ocpqp_ipm): carried slacks, bound residuals (zero to rounding)
+    // one bound pair of the iterate as a sweep sees it (oracle ocpqp_ipm): carried slacks
     struct PairL { T u, ll, lu, tl, tu, rl, ru; };
     auto pair_at = [&](const T *ivk, int k, int i) {
         PairL p;
         const T ul = NMPC_LD(w.ul, k * NU + i);
         p.u = NMPC_LD(ivk, i); p.ll = NMPC_LD(ivk, 4 + i); p.lu = NMPC_LD(ivk, 8 + i);
         p.tl = NMPC_LD(ivk, IV_TL + i); p.tu = NMPC_LD(ivk, IV_TU + i);
-        p.rl = (p.u - (c.lbu[i] - ul)) - p.tl;
-        p.ru = ((c.ubu[i] - ul) - p.u) - p.tu;
+        // residuals of the bound equations (HPIPM's res_d): identically zero in exact arithmetic with this feasible start; the oracle can feed
+        // them back (orc_config.qp_bound_res) and shows that nothing changes - the kernels leave them out (nmpc_team.hpp, Pair)
+        (void)ul;
+        p.rl = 0; p.ru = 0;
         return p;
     };
     // full direction of the pair for the affine step da and the final step d (slots 12.., 16.. of the iterate row)

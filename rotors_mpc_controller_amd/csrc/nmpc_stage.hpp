@@ -41,7 +41,6 @@ struct StageIn {
     double pc, pca;         // pin codes of inputs c | a (PINS)
     double u_it, ll_it, lu_it;   // iterate of input a (IPMV): input, multipliers of its two bounds ...
     double tl_it, tu_it;         // ... and their slacks (iterates of their own)
-    double u_itc;                // iterate of input c (IPMV): the stage is solved for the input STEP, b_k + B_k u_it enters column 15 of Abar
 };
 
 struct StageOut {
@@ -68,9 +67,10 @@ __device__ __forceinline__ StageSink<G, H, F> stage_sink(G g, H h, F f) { return
 // sink: what the stage hands to its caller while it runs (kept at the points of the instruction stream where the solver's sweep stored)
 //   grad(jt, a)  raw B'(Pbar Abar) tile jt (gradient rows of pinned inputs), hr(Hr) raw B'Pbar B;  only called when PINS and the stage has pins
 //   factors(o)   M, L^-1, 1/d are final
+// BtT: the input tiles TRANSPOSED (lane (j,a) of tile kt: B[4 kt + a][j]; pad rows zero) - the operand of B v, read only when PINS or IPMV
 template <bool PINS, bool IPMV, bool LAST, bool TRACK_GM, class Sink>
 __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double *sh, double *sHg, const int r,
-                                                     const double (&Aq0)[4], const double (&Aq1b)[4], const double (&Bt)[4],
+                                                     const double (&Aq0)[4], const double (&Aq1b)[4], const double (&Bt)[4], const double (&BtT)[4],
                                                      const StageIn &in, const bool pins_on, const bool ipm_on,
                                                      double (&Pt)[4][4], double &gm, bool &ok, bool &nanp, StageOut &o, Sink &&sink)
 {
@@ -79,10 +79,10 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
     T mask_a = T(1), mask_c = T(1), D_a = L.Rd_a, rhat_a = in.rk;
     if (IPMV) {
         // barrier terms of the interior-point iteration, solved for the STEP w of the inputs (u = u_it + w; oracle ocpqp_ipm):
-        // D = R + lam_l / t_l + lam_u / t_u, rhat = r + R u_it + (lam_l / t_l) rl - (lam_u / t_u) ru, and b_k + B_k u_it in column 15 below
-        const Pair<T> pr(in.u_it, in.ll_it, in.lu_it, in.tl_it, in.tu_it, L.lb_a - in.ul, L.ub_a - in.ul);
+        // D = R + lam_l / t_l + lam_u / t_u, rhat = r + R u_it, and b_k + B_k u_it in column 15 below
+        const Pair<T> pr(in.ll_it, in.lu_it, in.tl_it, in.tu_it);
         const T sg = pr.kl + pr.ku;
-        const T rh = in.rk + L.Rd_a * in.u_it + pr.kl * pr.rl - pr.ku * pr.ru;
+        const T rh = in.rk + L.Rd_a * in.u_it;
         if (PINS) { D_a = ipm_on ? L.Rd_a + sg : D_a; rhat_a = ipm_on ? rh : rhat_a; }
         else { D_a = L.Rd_a + sg; rhat_a = rh; }
     }
@@ -99,18 +99,17 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
         if (IPMV) { rhat_a = pinned_a ? -L.Rd_a * vpin_a : rhat_a; }
         else { D_a = L.Rd_a; rhat_a = pinned_a ? -L.Rd_a * vpin_a : in.rk; }
         any_pins = __ballot(pinned) != 0;
-        if (any_pins || IPMV) {                  // pinned inputs - and the inputs of an interior-point iterate - enter through b (column 15 of Abar)
-            const T vp = (pinned ? vpin_c : T(0)) + ((IPMV && ipm_on) ? in.u_itc : T(0));
-            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
-                const T sm = quad_sum(Bt[kt] * vp);
-                if (tc == 3 && L.natR[kt] >= 0) Aq1[kt] += sm;
-            }
+        if (any_pins || IPMV) {
+            // pinned inputs - and the inputs of an interior-point iterate - enter through b (column 15 of Abar): b += B v as one MFMA per row
+            // tile, v_j in lane (j, 3).  (Until round 5 a product + a two-step cross-lane sum per tile: 4 ds_bpermute each, the LDS pipe's
+            // latency in front of the W = P Abar products that need the column.)
+            (void)vpin_c;
+            const T vcol = tc == 3 ? (pinned_a ? vpin_a : T(0)) + ((IPMV && ipm_on) ? in.u_it : T(0)) : T(0);
+            NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = mfma44(BtT[kt], vcol, Aq1[kt]);
         }
     } else if (IPMV) {
-        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {        // b_k + B_k u_it (column 15 of Abar): the iterate of input c sits in lane (a,c)
-            const T sm = quad_sum(Bt[kt] * in.u_itc);
-            if (tc == 3 && L.natR[kt] >= 0) Aq1[kt] += sm;
-        }
+        const T vcol = tc == 3 ? in.u_it : T(0);             // b_k + B_k u_it (column 15 of Abar)
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) Aq1[kt] = mfma44(BtT[kt], vcol, Aq1[kt]);
     }
     // P B and Hr = B'PB first: the factorisation below depends on nothing else
     T WB[4], Hr = 0;

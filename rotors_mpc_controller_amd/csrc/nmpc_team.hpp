@@ -121,17 +121,18 @@ __device__ __forceinline__ T quad_sum(T x)     // over the 4 lanes 4q..4q+3 (the
 
 // One bound pair (lower, upper) of one input of the interior point's iterate: the slacks t_l, t_u are ITERATES of their own (stored with
 // the iterate, t <- t + alpha dt: HPIPM's form, oracle ocpqp_ipm) - never re-formed as u - lo, which cannot resolve the 1e-14 the central
-// path asks of an active bound's slack at mu = 1e-11.  rl, ru: residuals of the bound equations u - lo = t_l, hi - u = t_u (zero to
-// rounding; they enter the Newton system's right-hand side like HPIPM's res_d).  For an input step d: dt_l = d + rl, dt_u = -d + ru.
+// path asks of an active bound's slack at mu = 1e-11.  For an input step d: dt_l = d, dt_u = -d.  (HPIPM also feeds the residuals of the
+// bound equations, u - lo - t_l and hi - u - t_u, back into the right-hand side; here the start is feasible and t follows u exactly in exact
+// arithmetic, so they hold rounding of size ulp(u) - the oracle has them behind orc_config.qp_bound_res and tests/test_oracle_qp.py shows
+// iteration counts and commands unchanged with them; the kernels do not pay the ~6 FP64 operations per pair and sweep.)
 template <class T>
 struct Pair {
-    T tl, tu, itl, itu, kl, ku, rl, ru;
-    __device__ __forceinline__ Pair(T u, T ll, T lu, T tl_, T tu_, T lo, T hi)
+    T tl, tu, itl, itu, kl, ku;
+    __device__ __forceinline__ Pair(T ll, T lu, T tl_, T tu_)
     {
         tl = tl_; tu = tu_;
         itl = fast_rcp(tl); itu = fast_rcp(tu);
         kl = ll * itl; ku = lu * itu;
-        rl = (u - lo) - tl; ru = (hi - u) - tu;
     }
 };
 

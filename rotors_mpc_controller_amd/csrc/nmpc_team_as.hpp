@@ -354,6 +354,13 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         NMPC_UNROLL for (int t = 0; t < 12; t++) pfs[t] = a[t * 16];
     };
     const int rT = tc * 4 + ta;
+    // ... and its four input tiles once more, transposed (tile (kt, 2) through the swapped lane index): the operand of b += B v in the factor
+    // stages that have pinned inputs or barrier terms
+    T pft[4];
+    auto fetch_bt = [&](int k) {
+        const T *a = tAB + (size_t)k * TAB_ROWS + rT;
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) pft[kt] = a[(kt * 3 + 2) * 16];
+    };
     // linearisation point of stage k, natural row rr / input comp (cold start: x_k = x0, u_k = 0)
     auto xlin = [&](int k) -> T { return (warm && k > 0) ? (T)xi[(size_t)k * NX + rr] : x0r; };
     auto ulin = [&](int k, int comp) -> T { return warm ? (T)ui[(size_t)k * NU + comp] : T(0); };
@@ -402,7 +409,9 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     auto sweepA = [&](auto pins_tag, auto ipm_tag) {
         constexpr bool PINS = decltype(pins_tag)::value;
         constexpr bool IPMV = decltype(ipm_tag)::value;     // interior-point iteration: barrier terms on the input Hessian, nothing pinned
-        T Aq0[4], Aq1b[4], Bt[4];
+        T Aq0[4], Aq1b[4], Bt[4], BtT[4];       // BtT: the input tiles transposed (operand of b += B v: pinned values, the interior point's inputs)
+        constexpr bool NEED_BT = PINS || IPMV;
+        NMPC_UNROLL for (int kt = 0; kt < 4; kt++) BtT[kt] = 0;
         auto load_tiles = [&]() {
             NMPC_UNROLL for (int kt = 0; kt < 4; kt++) {
                 const int l = natR[kt] >= 0 ? natR[kt] : 0;
@@ -411,9 +420,14 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 Aq0[kt] = real ? a0 : T(0);
                 Aq1b[kt] = real ? (tc < 3 ? a1 : bv_) : ((kt == 3 && ta == 3 && tc == 3) ? T(1) : T(0));
                 Bt[kt] = real ? bb : T(0);
+                if (NEED_BT) {
+                    const int lc = natC[kt] >= 0 ? natC[kt] : 0;
+                    const T bt = sB[lc * 4 + ta];
+                    BtT[kt] = natC[kt] >= 0 ? bt : T(0);
+                }
             }
         };
-        if (SHARED) load_tiles(); else fetch_stage(ks, r);
+        if (SHARED) load_tiles(); else { fetch_stage(ks, r); if (NEED_BT) fetch_bt(ks); }
         T Pt[4][4];
         if (ks == N - 1) {
             // terminal cost: QdN on the diagonal, q_N = WqN (x_N - yref_e) in row / column 15
@@ -445,20 +459,21 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         T n_xl = xlin(ks), n_ul = ulin(ks, cu);
         T n_pc = PINS ? tIV[ks * IV_ROWS + 16 + j] : T(0);
         T n_pca = PINS ? tIV[ks * IV_ROWS + 16 + ta] : T(0), n_ulc = PINS ? ulin(ks, j) : T(0);
-        T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0, n_uc = 0;       // the iterate of input a - and the input of component c - (interior-point variant)
+        T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0;                 // the iterate of input a (interior-point variant)
         if (IPMV) {
             const T *ivn = tIV + ks * IV_ROWS;
-            n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta]; n_uc = ivn[j];
+            n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta];
         }
         auto stage = [&](int k, auto last_tag, auto lds_tag) {
             constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
             constexpr bool LDSST = decltype(lds_tag)::value;      // the factors of this stage stay in LDS
             if (!SHARED) {
                 NMPC_UNROLL for (int kt = 0; kt < 4; kt++) { Aq0[kt] = pfs[kt * 3]; Aq1b[kt] = pfs[kt * 3 + 1]; Bt[kt] = pfs[kt * 3 + 2]; }
-                if (!LAST) fetch_stage(k - 1, r);
+                if (NEED_BT) { NMPC_UNROLL for (int kt = 0; kt < 4; kt++) BtT[kt] = pft[kt]; }
+                if (!LAST) { fetch_stage(k - 1, r); if (NEED_BT) fetch_bt(k - 1); }
             }
             T *lmk = tLM + k * TLM_ROWS;
-            const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu, tl_it = n_tl, tu_it = n_tu, u_itc = n_uc;
+            const T ul = n_ul, pc = n_pc, pca = n_pca, ulc = n_ulc, u_it = n_u, ll_it = n_ll, lu_it = n_lu, tl_it = n_tl, tu_it = n_tu;
             // r_k must be a ROUNDED product in both variants (the pins variant passes it through LDS): left to
             // -ffp-contract the first-pass variant fuses it into gu = B'h + r_k, one rounding less, and a result
             // would depend on which variant last factorised a stage - i.e. on the wave-mates of an instance
@@ -472,12 +487,12 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 if (PINS) { n_pc = tIV[(k - 1) * IV_ROWS + 16 + j]; n_pca = tIV[(k - 1) * IV_ROWS + 16 + ta]; n_ulc = ulin(k - 1, j); }
                 if (IPMV) {
                     const T *ivn = tIV + (k - 1) * IV_ROWS;
-                    n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta]; n_uc = ivn[j];
+                    n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta];
                 }
             }
             StageIn sin;
             sin.rk = rk; sin.q_r = q_r; sin.ul = ul; sin.ulc = ulc; sin.pc = pc; sin.pca = pca; sin.u_it = u_it; sin.ll_it = ll_it; sin.lu_it = lu_it;
-            sin.tl_it = tl_it; sin.tu_it = tu_it; sin.u_itc = u_itc;
+            sin.tl_it = tl_it; sin.tu_it = tu_it;
             StageOut so;
             // the stage itself: nmpc_stage.hpp (one source for this sweep and the block sweeps of nmpc_block.hpp).  Stores happen where they
             // always did: gradient rows of pinned stages while X is formed, the factors as soon as M is final
@@ -495,7 +510,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                         if (LDSST) sLM[k * LMR + 80 + rs] = f.ra; else lmk[TLM_RINV + rs] = f.ra;
                     }
                 });
-            riccati_factor_stage<PINS, IPMV, LAST, true>(SL, sh, sHg, r, Aq0, Aq1b, Bt, sin, pol, true, Pt, gm, ok, nanp, so, sink);
+            riccati_factor_stage<PINS, IPMV, LAST, true>(SL, sh, sHg, r, Aq0, Aq1b, Bt, BtT, sin, pol, true, Pt, gm, ok, nanp, so, sink);
             if (!LAST) {
                 if (!IPMV && have_tP && k <= wnd) {
                     T *cp = tP + (size_t)k * TP_ROWS + r;
@@ -600,17 +615,15 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 const T uf = ut + (tc == 0 ? o.u : T(0));
                 NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], uf, xn[it]);
                 // affine-scaling step of input a in lane (a,0): step-length terms of the predictor, step kept for the corrector
-                const T d = ut;
-                const T lo = lb_a - ul, hi = ub_a - ul;
-                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lo, hi);
-                const T el = d + pr.rl, eu = pr.ru - d;                     // affine directions of the two slacks
-                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
-                // inverse step lengths: -el/tl, -eu/tu, -dla/ll = 1 + el/tl, -dua/lu = 1 + eu/tu
-                const T a1 = el * pr.itl, a2 = eu * pr.itu;
-                rmaxB = fmax(rmaxB, fmax(fmax(-a1, -a2), fmax(T(1) + a1, T(1) + a2)));
-                s2B += dla * el + dua * eu;
+                const T d = ut;                                             // (the slacks move with it: dt_l = d, dt_u = -d)
+                const Pair<T> pr(o.ll, o.lu, o.tl, o.tu);
+                const T dla = -o.ll - pr.kl * d, dua = -o.lu + pr.ku * d;
+                // inverse step lengths: -d/tl, d/tu, -dla/ll = 1 + d/tl, -dua/lu = 1 - d/tu
+                const T a1 = d * pr.itl, a2 = d * pr.itu;
+                rmaxB = fmax(rmaxB, fmax(fmax(-a1, a2), fmax(T(1) + a1, T(1) - a2)));
+                s2B += dla * d - dua * d;
                 ivk[cslot] = d;
-                (void)pc;
+                (void)pc; (void)ul;
             } else {
                 NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
                 // KKT check of the pass, input a in lane (a,0): a free input must sit inside its box; a pinned one
@@ -764,7 +777,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         }
     };
     T rmaxE = 0, dmaxE = 0;        // sweep E: largest inverse step length (floor tau), largest |d| / box width
-    struct OpsD { T mn[4], y, ri, u, ll, lu, tl, tu, ua, ul; };
+    struct OpsD { T mn[4], y, ri, ll, lu, tl, tu, ua; };
     // ================= sweep D: backward homogeneous solve of the corrector: g = dr + B'pi, m0 = L^-1 g, pi_k = Abar'pi - Mbar'm0
     auto sweepD = [&](auto) {
         T Aq0[4], Aq1z[4], Bt[4];
@@ -784,7 +797,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         auto fetch_sc = [&](int kq, OpsD &o) {
             const int k = kq > 0 ? kq : 0;
             const T *ivn = tIV + k * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
+            o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta];
         };
         auto fetch_d = [&](int kq, OpsD &o) {           // factors from the HBM scratch (clamped index, see sweep B)
             const int k = kq > 0 ? kq : 0;
@@ -808,11 +821,10 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             }
             T drt;
             {
-                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lb_a - o.ul, ub_a - o.ul);
+                const Pair<T> pr(o.ll, o.lu, o.tl, o.tu);
                 const T da = o.ua;                                           // the affine step
-                const T el = da + pr.rl, eu = pr.ru - da;
-                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
-                const T cl = dla * el, cu = dua * eu;
+                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
                 drt = tc == 0 ? -(sigmu - cl) * pr.itl + (sigmu - cu) * pr.itu : T(0);
             }
             const T g = mfma44(Bt[2], pit[2], mfma44(Bt[0], pit[0], drt)) + mfma44(Bt[3], pit[3], mfma44(Bt[1], pit[1], T(0)));
@@ -850,8 +862,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 fetch_sc(kl - 2, on2);
                 OpsD ol2;
                 auto scalars = [&](OpsD &o, int k) {
-                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua; o.ul = on.ul;
-                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua; on.ul = on2.ul;
+                    o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua;
+                    on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua;
                     fetch_sc(k - 2, on2);
                 };
                 fetch_d_lds(kl - 1, ol);
@@ -885,12 +897,12 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = 0;
         const T one15 = (ta == 3 && tc == 0) ? T(1) : T(0);        // homogeneous coordinate, for the m term only
         T rmx = c.tau, dmx = 0;
-        struct OpsE { T mt[4], z, u, ll, lu, tl, tu, ua, ul, ab[SHARED ? 1 : 12]; };
+        struct OpsE { T mt[4], z, ll, lu, tl, tu, ua, ab[SHARED ? 1 : 12]; };
         const int kl = LDSC ? (lstg < N ? lstg : N) : 0;
         const int dslot = tc == 0 ? 16 + ta : 20 + ta;
         auto fetch_sc = [&](int k, OpsE &o) {
             const T *ivn = tIV + k * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta]; o.ul = ulin(k, ta);
+            o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta];
         };
         auto fetch_e = [&](int kq, OpsE &o) {
             const int k = kq < N ? kq : N - 1;
@@ -924,17 +936,15 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             const T ut = mfma44_na(o.z, v, T(0));
             NMPC_UNROLL for (int it = 0; it < 4; it++) xn[it] = mfma44(BT[it], ut, xn[it]);
             {
-                const Pair<T> pr(o.u, o.ll, o.lu, o.tl, o.tu, lb_a - o.ul, ub_a - o.ul);
+                const Pair<T> pr(o.ll, o.lu, o.tl, o.tu);
                 const T da = o.ua;
-                const T el = da + pr.rl, eu = pr.ru - da;
-                const T dla = -o.ll - pr.kl * el, dua = -o.lu - pr.ku * eu;
-                const T cl = dla * el, cu = dua * eu;
+                const T dla = -o.ll - pr.kl * da, dua = -o.lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
                 const T d = da + ut;
                 ivk[dslot] = d;
-                const T dtl = d + pr.rl, dtu = pr.ru - d;                   // directions of the two slacks
-                const T dl = -o.ll - (cl - sigmu) * pr.itl - pr.kl * dtl;
-                const T du = -o.lu - (cu - sigmu) * pr.itu - pr.ku * dtu;
-                rmx = fmax(rmx, fmax(-dtl * pr.itl, -dtu * pr.itu));
+                const T dl = -o.ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                const T du = -o.lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                rmx = fmax(rmx, fmax(-d * pr.itl, d * pr.itu));
                 rmx = fmax(rmx, fmax(-dl * fast_rcp(o.ll), -du * fast_rcp(o.lu)));
                 dmx = fmax(dmx, fabs(d) * iw_a);
             }
@@ -952,8 +962,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 fetch_sc(1 < N ? 1 : 0, on2);
                 OpsE ol2;
                 auto scalars = [&](OpsE &o, int k) {
-                    o.u = on.u; o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua; o.ul = on.ul;
-                    on.u = on2.u; on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua; on.ul = on2.ul;
+                    o.ll = on.ll; o.lu = on.lu; o.tl = on.tl; o.tu = on.tu; o.ua = on.ua;
+                    on.ll = on2.ll; on.lu = on2.lu; on.tl = on2.tl; on.tu = on2.tu; on.ua = on2.ua;
                     fetch_sc(k + 2 < N ? k + 2 : N - 1, on2);
                 };
                 fetch_e_lds(0, ol);
@@ -985,12 +995,11 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         T ms = 0;
         constexpr int CHF = 5;
         for (int k0 = 0; k0 < N; k0 += 4 * CHF) {
-            T f_ul[CHF], f_u[CHF], f_ll[CHF], f_lu[CHF], f_tl[CHF], f_tu[CHF], f_ua[CHF], f_d[CHF];
+            T f_u[CHF], f_ll[CHF], f_lu[CHF], f_tl[CHF], f_tu[CHF], f_ua[CHF], f_d[CHF];
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
                 const int kq = k0 + 4 * i + tc;
                 const int k = kq < N ? kq : N - 1;
                 const T *ivn = tIV + k * IV_ROWS;
-                f_ul[i] = ulin(k, ta);
                 f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_tl[i] = ivn[IV_TL + ta]; f_tu[i] = ivn[IV_TU + ta];
                 f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
             }
@@ -1000,16 +1009,13 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 // a lane past the horizon repeats stage N - 1 into the spare slots of that stage
                 T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
                 T u = f_u[i], ll = f_ll[i], lu = f_lu[i], tl = f_tl[i], tu = f_tu[i];
-                const T lo = lb_a - f_ul[i], hi = ub_a - f_ul[i];
-                const Pair<T> pr(u, ll, lu, tl, tu, lo, hi);
+                const Pair<T> pr(ll, lu, tl, tu);
                 const T da = f_ua[i], d = f_d[i];
-                const T el = da + pr.rl, eu = pr.ru - da;
-                const T dla = -ll - pr.kl * el, dua = -lu - pr.ku * eu;
-                const T cl = dla * el, cu = dua * eu;
-                const T dtl = d + pr.rl, dtu = pr.ru - d;
-                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * dtl;
-                const T du = -lu - (cu - sigmu) * pr.itu - pr.ku * dtu;
-                u += alpha * d; tl += alpha * dtl; tu += alpha * dtu; ll += alpha * dl; lu += alpha * du;
+                const T dla = -ll - pr.kl * da, dua = -lu + pr.ku * da;
+                const T cl = dla * da, cu = -dua * da;
+                const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
+                const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
+                u += alpha * d; tl += alpha * d; tu -= alpha * d; ll += alpha * dl; lu += alpha * du;
                 ivk[live ? ta : 20 + ta] = u; ivk[live ? 4 + ta : 20 + ta] = ll; ivk[live ? 8 + ta : 20 + ta] = lu;
                 ivk[live ? IV_TL + ta : 20 + ta] = tl; ivk[live ? IV_TU + ta : 20 + ta] = tu;
                 // active-set guess for a later attempt: a bound whose multiplier exceeds its slack

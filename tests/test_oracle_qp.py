@@ -442,3 +442,31 @@ def test_carried_slacks_end_the_late_iterations_without_a_nan(seed, inst, warm):
     assert st.mu <= c.qp_tol_comp and st.res_comp <= 1e-8 and st.rho <= c.qp_tol_stat
     # the bounds hold to the resolution of the inputs
     assert (un >= np.array(c.lbu) - 1e-13).all() and (un <= np.array(c.ubu) + 1e-13).all()
+
+
+def test_feeding_the_bound_residuals_back_changes_nothing():
+    """HPIPM feeds the residuals of the bound equations (res_d: u - lo - t_l, hi - u - t_u) into every Newton system.  With this iteration's
+    feasible start and carried slacks they are zero in exact arithmetic - what they hold is rounding of size ulp(u) - so the kernels leave them
+    out (six FP64 operations per bound pair and sweep).  The oracle keeps them behind qp_bound_res: same iteration counts on every instance,
+    commands equal to 1e-11, on the reference's vehicle (plain interior point, near-hover and aggressive) and on the fuzz draws whose late
+    iterations were the reason for carrying the slacks."""
+    from tests.fuzz_draws import draw, oracle_config
+    cases = []
+    for dist, seed in ((NEAR_HOVER, 0), (AGGRESSIVE, 0)):
+        c = O.default_config(qp_gamma=0.0, qp_polish=0)
+        cases.append((c, sample_x0(256, seed, **dist)) + O.hover_yref(c))
+    for seed in (1910, 3043, 3072):
+        over, x0, yref, ye, _, _, _ = draw(seed)
+        cases.append((oracle_config(over), x0, yref, ye))
+    for c, x0, yref, ye in cases:
+        c.qp_bound_res = 0
+        a = O.solve_batch(c, x0, yref, ye, want_traj=True)
+        c.qp_bound_res = 1
+        b = O.solve_batch(c, x0, yref, ye, want_traj=True)
+        np.testing.assert_array_equal(a["status"], b["status"])
+        np.testing.assert_array_equal(a["iters"], b["iters"])
+        np.testing.assert_array_equal(a["passes"], b["passes"])
+        ok = a["status"] == 0
+        scale = max(1.0, float(np.abs(a["u0"][ok]).max()))
+        assert np.abs(a["u0"][ok] - b["u0"][ok]).max() <= 1e-11 * scale
+        assert np.abs(a["u"][ok] - b["u"][ok]).max() <= 1e-9 * scale
