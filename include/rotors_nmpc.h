@@ -49,7 +49,7 @@ extern "C" {
                               SURVEY 8) and outside the 1e-6 the path is held to: retired.)                                   */
 #define NMPC_DTYPE_F32IO 2 /* device buffers float, arithmetic and workspace DOUBLE: the FP64 tile kernels read and write the
                               caller's float arrays directly (half the compulsory bytes of F64, u0 exact to float rounding of
-                              the inputs).  Needs the default path: team mapping, qp_polish on, no condensing               */
+                              the inputs).  Needs the team mapping without condensing (the default flags)                   */
 
 /* flags */
 #define NMPC_FLAG_SHARE_COLD_START 1u /* cold start: all stages share one (A,B,b); linearise once */

@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../include/rotors_nmpc.h"
@@ -309,13 +310,11 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
         return bad("nmpc_create: only sim_method_num_stages = 2 (explicit midpoint, controller.py:187) is built");
     if (cfg->sim_num_steps < 1) return bad("nmpc_create: sim_num_steps must be >= 1");
     if (cfg->dtype != NMPC_DTYPE_F64 && cfg->dtype != NMPC_DTYPE_F32 && cfg->dtype != NMPC_DTYPE_F32IO) return bad("nmpc_create: bad dtype");
-    // FP32 buffers (NMPC_DTYPE_F32 = NMPC_DTYPE_F32IO since round 5: the arithmetic is FP64 either way, include/rotors_nmpc.h)
+    // FP32 buffers (NMPC_DTYPE_F32 = NMPC_DTYPE_F32IO since round 5: the arithmetic is FP64 either way, include/rotors_nmpc.h): every kernel of the
+    // team mapping is instantiated for float arrays; the fidelity kernels of the lane layout are not
     if (cfg->dtype != NMPC_DTYPE_F64) {
-        const bool ok = (cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP) && cfg->qp_polish &&
-                        cfg->qp_polish_mu >= cfg->qp_mu0 &&
-                        cfg->sim_num_steps <= AS_MAX_STEPS && !(cfg->qp_mu0 <= cfg->qp_tol_comp);
-        if (!ok) return bad("nmpc_create: FP32 buffers (NMPC_DTYPE_F32 / NMPC_DTYPE_F32IO) run on the default path only (team mapping, "
-                            "qp_polish = 1 with its first attempt before any interior-point iteration, sim_num_steps <= 4, no condensing)");
+        const bool ok = (cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP);
+        if (!ok) return bad("nmpc_create: FP32 buffers (NMPC_DTYPE_F32 / NMPC_DTYPE_F32IO) need the team mapping without condensing (the default)");
     }
     if ((cfg->flags & NMPC_FLAG_TEAM_MAPPING) && !(cfg->flags & NMPC_FLAG_CONDENSED_QP) && cfg->sim_num_steps > AS_MAX_STEPS)
         return bad("nmpc_create: the team mapping is built for sim_num_steps <= 4 (controller.py:188 sets 2); clear NMPC_FLAG_TEAM_MAPPING for more");
@@ -680,37 +679,11 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
     return 0;
 }
 
-// NMPC_DTYPE_F32IO: FP64 arithmetic and workspace on the caller's FP32 device arrays (default path only, checked at create)
-static int launch_f32io(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
-                        const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
-{
-    Consts<double> c;
-    fill_consts(s->cfg, c);
-    const bool cold = (x_init == nullptr || u_init == nullptr);
-    c.shared = (cold && (s->cfg.flags & NMPC_FLAG_SHARE_COLD_START)) ? 1 : 0;
-    Work<double> w;
-    w.Bp = s->Bp;
-    w.AB = (double *)s->AB; w.bv = (double *)s->bv; w.qr = (double *)s->qr; w.xl = (double *)s->xl; w.ul = (double *)s->ul;
-    w.LM = (double *)s->LM; w.iv = (double *)s->iv; w.iters = s->d_iters; w.status = s->d_status;
-    w.prof = s->d_prof; w.npol = s->d_npol; w.tAB = (double *)s->tAB; w.gbase = s->d_gbase;
-    Inputs<float> in;
-    in.x0 = (const float *)x0; in.yref = (const float *)yref; in.yref_e = (const float *)yref_e;
-    in.x_init = cold ? nullptr : (const float *)x_init; in.u_init = cold ? nullptr : (const float *)u_init;
-    in.yref_bcast = bcast;
-    Outputs<float> out;
-    out.u0 = (float *)u0; out.x_out = (float *)x_out; out.u_out = (float *)u_out; out.status = status;
-    TeamWork<double> tw;
-    tw.tLM = (double *)s->LM; tw.tIV = (double *)s->iv;
-    tw.tP = c.polish_ckpt > 0 ? (double *)s->tP : nullptr;
-    int tpw = s->team_tpw;
-    if (tpw == 0) tpw = (B >= 2048) ? 4 : (B >= 512 ? 2 : 1);
-    if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
-    return launch_split<float>(s, c, w, in, out, tw, B, tpw, st);
-}
-
-// NMPC_DTYPE_F64: the default path (launch_split), the one-launch interior-point kernel k_team_qp for every other team-mapped
-// configuration, and the two fidelity paths of the lane layout (k_prepare + k_ipm | k_cond_ipm)
-static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
+// One solve.  TI = element type of the caller's device arrays (double; float for NMPC_DTYPE_F32IO / _F32): arithmetic and workspace are
+// double either way.  The default path (launch_split), the one-launch interior-point kernel k_team_qp for every other team-mapped
+// configuration, and - FP64 arrays only - the two fidelity paths of the lane layout (k_prepare + k_ipm | k_cond_ipm)
+template <class TI>
+static int launch_any(nmpc_solver *s, int B, const void *x0, const void *yref, const void *yref_e, int bcast,
                       const void *x_init, const void *u_init, void *u0, int32_t *status, void *x_out, void *u_out, hipStream_t st)
 {
     using T = double;
@@ -726,12 +699,12 @@ static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, c
     w.npol = s->d_npol;
     w.tAB = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) ? (T *)s->tAB : nullptr;
     w.gbase = (T *)s->d_gbase;
-    Inputs<T> in;
-    in.x0 = (const T *)x0; in.yref = (const T *)yref; in.yref_e = (const T *)yref_e;
-    in.x_init = cold ? nullptr : (const T *)x_init; in.u_init = cold ? nullptr : (const T *)u_init;
+    Inputs<TI> in;
+    in.x0 = (const TI *)x0; in.yref = (const TI *)yref; in.yref_e = (const TI *)yref_e;
+    in.x_init = cold ? nullptr : (const TI *)x_init; in.u_init = cold ? nullptr : (const TI *)u_init;
     in.yref_bcast = bcast;
-    Outputs<T> out;
-    out.u0 = (T *)u0; out.x_out = (T *)x_out; out.u_out = (T *)u_out; out.status = status;
+    Outputs<TI> out;
+    out.u0 = (TI *)u0; out.x_out = (TI *)x_out; out.u_out = (TI *)u_out; out.status = status;
     const dim3 grid((B + 63) / 64), block(64);
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[0], st));
     const bool team = (s->cfg.flags & NMPC_FLAG_TEAM_MAPPING) && !(s->cfg.flags & NMPC_FLAG_CONDENSED_QP);
@@ -749,7 +722,7 @@ static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, c
         // settle.  Taken when the QP starts with an active-set attempt (polish on, first attempt before any interior-point iteration).
         const bool split = s->team_split && s->cfg.qp_polish && s->cfg.qp_polish_budget > 0 &&
                            s->cfg.qp_polish_passes > 0 && s->cfg.qp_polish_mu >= s->cfg.qp_mu0 && !(s->cfg.qp_mu0 <= s->cfg.qp_tol_comp);
-        if (split) return launch_split<double>(s, c, w, in, out, tw, B, tpw, st);
+        if (split) return launch_split<TI>(s, c, w, in, out, tw, B, tpw, st);
         // every other tile-form solve - qp_polish = 0, an attempt schedule that starts with interior-point iterations,
         // NMPC_TEAM_SPLIT=0 - is ONE launch of k_team_qp (the same sweeps as the split path, nmpc_team_as.hpp)
         WorkList wl;
@@ -766,7 +739,10 @@ static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, c
         s->last_shared = c.shared != 0;
         return 0;
     }
-    // lane layout ([row][Bp] workspace): linearisation as a launch of its own, then the QP
+    // lane layout ([row][Bp] workspace; FP64 arrays only, checked at create): linearisation as a launch of its own, then the QP
+    if constexpr (!std::is_same<TI, double>::value) {
+        return s->fail(NMPC_EARG, "solve_batch: FP32 buffers need the team mapping without condensing");
+    } else {
     HIP_TRY(s, hipMemsetAsync(s->d_npol, 0, (size_t)B * sizeof(int32_t), st));   // (the lane kernels make no active-set passes)
     hipLaunchKernelGGL(k_prepare<T>, grid, block, 0, st, c, w, in, B);
     HIP_TRY(s, hipGetLastError());
@@ -791,6 +767,7 @@ static int launch_f64(nmpc_solver *s, int B, const void *x0, const void *yref, c
     s->last_split = false;
     s->last_shared = c.shared != 0;
     return 0;
+    }
 }
 
 extern "C" {
@@ -805,8 +782,8 @@ int nmpc_solve_batch_device(nmpc_solver *s, int B, const void *x0, const void *y
     if ((x_init == nullptr) != (u_init == nullptr)) return s->fail(NMPC_EARG, "solve_batch: x_init and u_init must both be given or both be NULL");
     HIP_TRY(s, hipSetDevice(s->cfg.device));
     hipStream_t st = (hipStream_t)hip_stream;
-    if (s->cfg.dtype == NMPC_DTYPE_F32IO) return launch_f32io(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
-    return launch_f64(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
+    if (s->cfg.dtype == NMPC_DTYPE_F32IO) return launch_any<float>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
+    return launch_any<double>(s, B, x0, yref, yref_e, yref_bcast, x_init, u_init, u0, status, x_out, u_out, st);
 }
 
 static int ensure_staging(nmpc_solver *s, size_t B)

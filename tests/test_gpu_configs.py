@@ -337,9 +337,16 @@ def test_f32io_warm_start_aggressive_and_work_list():
     np.testing.assert_array_equal(a2["status"], b2["status"])
     np.testing.assert_allclose(a2["u0"], b2["u0"], rtol=0, atol=1e-6)
     np.testing.assert_allclose(a2["x"], b2["x"], rtol=0, atol=2e-6)
+    # the plain interior point (k_team_qp) on FP32 buffers: every kernel of the team mapping takes float arrays since round 5
+    p32, p64 = make_solver(dtype=_lib.DTYPE_F32IO, max_batch=B, qp_polish=0), make_solver(max_batch=B, qp_polish=0)
+    c, d = p32.solve_batch(x0[:128], yref, ye), p64.solve_batch(x0[:128], yref, ye)
+    np.testing.assert_array_equal(c["status"], d["status"])
+    np.testing.assert_array_equal(p32.iterations(128), p64.iterations(128))
+    ok = d["status"] == 0
+    np.testing.assert_allclose(c["u0"][ok], d["u0"][ok], rtol=0, atol=1e-6)
     from rotors_mpc_controller_amd.solver import NmpcError
     with pytest.raises(NmpcError):
-        make_solver(dtype=_lib.DTYPE_F32IO, qp_polish=0)            # default path only
+        make_solver(dtype=_lib.DTYPE_F32IO, flags=0)                # the lane layout's fidelity kernels take FP64 arrays only
 
 
 def test_config5_gpu_uncondensed_agrees_with_block_120_condensing():
