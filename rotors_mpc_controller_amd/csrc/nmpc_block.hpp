@@ -206,7 +206,9 @@ __device__ __forceinline__ void block_sweep(const Consts<double> &c, const Block
         o.u = 0; o.ll = 0; o.lu = 0; o.tl = 1; o.tu = 1;                 // the iterate of input a (interior-point iteration)
         if (TAIL) {
             const T *ivn = tIV + kc * IV_ROWS;
-            o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta];
+            o.u = ivn[ta];
+            { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); o.ll = p_.x; o.lu = p_.y; }
+            { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); o.tl = p_.x; o.tu = p_.y; }
         }
     };
 

@@ -119,6 +119,18 @@ __device__ __forceinline__ T quad_sum(T x)     // over the 4 lanes 4q..4q+3 (the
     return x;
 }
 
+// Where the interior point's iterate of input a lives in a stage's row of tIV: u at a; the PAIRS (lam_l, lam_u) at IVP_L + 2a and (t_l, t_u)
+// at IVP_T + 2a, 16-byte aligned, so that a sweep fetches each pair with one global_load_dwordx4 (until round 5 the four values sat 32 bytes
+// apart: four loads - carrying the slacks had made the interior-point kernel 8 % slower than round 4, mostly through its load count).
+constexpr int IVP_L = 4, IVP_T = 36;
+struct D2 { double x, y; };
+__device__ __forceinline__ D2 ld2(const double *p)
+{
+    const double2 v = *reinterpret_cast<const double2 *>(p);
+    return D2{v.x, v.y};
+}
+__device__ __forceinline__ void st2(double *p, double x, double y) { *reinterpret_cast<double2 *>(p) = make_double2(x, y); }
+
 // One bound pair (lower, upper) of one input of the interior point's iterate: the slacks t_l, t_u are ITERATES of their own (stored with
 // the iterate, t <- t + alpha dt: HPIPM's form, oracle ocpqp_ipm) - never re-formed as u - lo, which cannot resolve the 1e-14 the central
 // path asks of an active bound's slack at mu = 1e-11.  For an input step d: dt_l = d, dt_u = -d.  (HPIPM also feeds the residuals of the

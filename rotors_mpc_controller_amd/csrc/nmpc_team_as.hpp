@@ -462,7 +462,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0;                 // the iterate of input a (interior-point variant)
         if (IPMV) {
             const T *ivn = tIV + ks * IV_ROWS;
-            n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta];
+            n_u = ivn[ta]; { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); n_ll = p_.x; n_lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); n_tl = p_.x; n_tu = p_.y; }
         }
         auto stage = [&](int k, auto last_tag, auto lds_tag) {
             constexpr bool LAST = decltype(last_tag)::value;      // stage 0: no Riccati update needed
@@ -487,7 +487,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 if (PINS) { n_pc = tIV[(k - 1) * IV_ROWS + 16 + j]; n_pca = tIV[(k - 1) * IV_ROWS + 16 + ta]; n_ulc = ulin(k - 1, j); }
                 if (IPMV) {
                     const T *ivn = tIV + (k - 1) * IV_ROWS;
-                    n_u = ivn[ta]; n_ll = ivn[4 + ta]; n_lu = ivn[8 + ta]; n_tl = ivn[IV_TL + ta]; n_tu = ivn[IV_TU + ta];
+                    n_u = ivn[ta]; { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); n_ll = p_.x; n_lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); n_tl = p_.x; n_tu = p_.y; }
                 }
             }
             StageIn sin;
@@ -581,7 +581,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             }
             o.ul = ulin(k, ta);
             o.pc = PINS ? tIV[k * IV_ROWS + 16 + ta] : T(0);
-            if (IPMV) { const T *ivn = tIV + k * IV_ROWS; o.u = ivn[ta]; o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; }
+            if (IPMV) { const T *ivn = tIV + k * IV_ROWS; o.u = ivn[ta]; { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); o.ll = p_.x; o.lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); o.tl = p_.x; o.tu = p_.y; } }
             if (!SHARED) {
                 const T *a = tAB + (size_t)k * TAB_ROWS + rT;
                 NMPC_UNROLL for (int t = 0; t < 12; t++) o.ab[t] = a[t * 16];
@@ -697,9 +697,9 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 T n_ul = ulin(0, ta), n_pc = PINS ? tIV[16 + ta] : T(0);
                 T n_u = 0, n_ll = 0, n_lu = 0, n_tl = 0, n_tu = 0, m_u = 0, m_ll = 0, m_lu = 0, m_tl = 0, m_tu = 0;      // interior-point variant: the iterate two stages ahead
                 if (IPMV) {
-                    n_u = tIV[ta]; n_ll = tIV[4 + ta]; n_lu = tIV[8 + ta]; n_tl = tIV[IV_TL + ta]; n_tu = tIV[IV_TU + ta];
+                    n_u = tIV[ta]; { const D2 p_ = ld2(tIV + IVP_L + 2 * ta); n_ll = p_.x; n_lu = p_.y; } { const D2 p_ = ld2(tIV + IVP_T + 2 * ta); n_tl = p_.x; n_tu = p_.y; }
                     const T *iv1 = tIV + (1 < N ? 1 : 0) * IV_ROWS;
-                    m_u = iv1[ta]; m_ll = iv1[4 + ta]; m_lu = iv1[8 + ta]; m_tl = iv1[IV_TL + ta]; m_tu = iv1[IV_TU + ta];
+                    m_u = iv1[ta]; { const D2 p_ = ld2(iv1 + IVP_L + 2 * ta); m_ll = p_.x; m_lu = p_.y; } { const D2 p_ = ld2(iv1 + IVP_T + 2 * ta); m_tl = p_.x; m_tu = p_.y; }
                 }
                 // the factors of stage k + 1 leave LDS before stage k computes (two operand sets, alternating): a stage is a short
                 // chain of dependent MFMAs and would otherwise open with an exposed LDS round trip
@@ -712,7 +712,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                     if (IPMV) {
                         n_u = m_u; n_ll = m_ll; n_lu = m_lu; n_tl = m_tl; n_tu = m_tu;
                         const T *ivn = tIV + (k + 2 < N ? k + 2 : N - 1) * IV_ROWS;
-                        m_u = ivn[ta]; m_ll = ivn[4 + ta]; m_lu = ivn[8 + ta]; m_tl = ivn[IV_TL + ta]; m_tu = ivn[IV_TU + ta];
+                        m_u = ivn[ta]; { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); m_ll = p_.x; m_lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); m_tl = p_.x; m_tu = p_.y; }
                     }
                 };
                 fetch_ops_lds(0, ol);
@@ -768,10 +768,8 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 if (k < N && tc == 0 && mine) {
                     T *ivk = tIV_own + k * IV_ROWS;
                     ivk[ta] = v;
-                    ivk[IV_TL + ta] = v - lo;
-                    ivk[IV_TU + ta] = hi - v;
-                    ivk[4 + ta] = c.mu0 / (v - lo);
-                    ivk[8 + ta] = c.mu0 / (hi - v);
+                    st2(ivk + IVP_T + 2 * ta, v - lo, hi - v);
+                    st2(ivk + IVP_L + 2 * ta, c.mu0 / (v - lo), c.mu0 / (hi - v));
                 }
             }
         }
@@ -797,7 +795,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         auto fetch_sc = [&](int kq, OpsD &o) {
             const int k = kq > 0 ? kq : 0;
             const T *ivn = tIV + k * IV_ROWS;
-            o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta];
+            { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); o.ll = p_.x; o.lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); o.tl = p_.x; o.tu = p_.y; } o.ua = ivn[12 + ta];
         };
         auto fetch_d = [&](int kq, OpsD &o) {           // factors from the HBM scratch (clamped index, see sweep B)
             const int k = kq > 0 ? kq : 0;
@@ -902,7 +900,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         const int dslot = tc == 0 ? 16 + ta : 20 + ta;
         auto fetch_sc = [&](int k, OpsE &o) {
             const T *ivn = tIV + k * IV_ROWS;
-            o.ll = ivn[4 + ta]; o.lu = ivn[8 + ta]; o.tl = ivn[IV_TL + ta]; o.tu = ivn[IV_TU + ta]; o.ua = ivn[12 + ta];
+            { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); o.ll = p_.x; o.lu = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); o.tl = p_.x; o.tu = p_.y; } o.ua = ivn[12 + ta];
         };
         auto fetch_e = [&](int kq, OpsE &o) {
             const int k = kq < N ? kq : N - 1;
@@ -1000,7 +998,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 const int kq = k0 + 4 * i + tc;
                 const int k = kq < N ? kq : N - 1;
                 const T *ivn = tIV + k * IV_ROWS;
-                f_u[i] = ivn[ta]; f_ll[i] = ivn[4 + ta]; f_lu[i] = ivn[8 + ta]; f_tl[i] = ivn[IV_TL + ta]; f_tu[i] = ivn[IV_TU + ta];
+                f_u[i] = ivn[ta]; { const D2 p_ = ld2(ivn + IVP_L + 2 * ta); f_ll[i] = p_.x; f_lu[i] = p_.y; } { const D2 p_ = ld2(ivn + IVP_T + 2 * ta); f_tl[i] = p_.x; f_tu[i] = p_.y; }
                 f_ua[i] = ivn[12 + ta]; f_d[i] = ivn[16 + ta];
             }
             NMPC_UNROLL for (int i = 0; i < CHF; i++) {
@@ -1016,8 +1014,10 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 const T dl = -ll - (cl - sigmu) * pr.itl - pr.kl * d;
                 const T du = -lu - (cu - sigmu) * pr.itu + pr.ku * d;
                 u += alpha * d; tl += alpha * d; tu -= alpha * d; ll += alpha * dl; lu += alpha * du;
-                ivk[live ? ta : 20 + ta] = u; ivk[live ? 4 + ta : 20 + ta] = ll; ivk[live ? 8 + ta : 20 + ta] = lu;
-                ivk[live ? IV_TL + ta : 20 + ta] = tl; ivk[live ? IV_TU + ta : 20 + ta] = tu;
+                // (a lane past the horizon stores into the spare slots 20..23 of stage N - 1)
+                ivk[live ? ta : 20 + ta] = u;
+                st2(ivk + (live ? IVP_L + 2 * ta : 20 + 2 * (ta & 1)), ll, lu);
+                st2(ivk + (live ? IVP_T + 2 * ta : 20 + 2 * (ta & 1)), tl, tu);
                 // active-set guess for a later attempt: a bound whose multiplier exceeds its slack
                 ivk[live ? 16 + ta : 20 + ta] = ll > tl ? T(-1) : (lu > tu ? T(1) : T(0));
                 ms += live ? ll * tl + lu * tu : T(0);
@@ -1042,10 +1042,11 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 const int kq = k0 + 4 * i + tc;
                 const bool live = kq < N;
                 T *ivk = tIV + (live ? kq : N - 1) * IV_ROWS;
-                ivk[live ? ta : 20 + ta] = w_u[i]; ivk[live ? 4 + ta : 20 + ta] = w_l[i]; ivk[live ? 8 + ta : 20 + ta] = w_h[i];
+                ivk[live ? ta : 20 + ta] = w_u[i];
+                st2(ivk + (live ? IVP_L + 2 * ta : 20 + 2 * (ta & 1)), w_l[i], w_h[i]);
                 const T lo = lb_a - w_ul[i], hi = ub_a - w_ul[i];
                 const T tl = w_u[i] - lo, tu = hi - w_u[i];                  // the slacks of the new iterate start on its inputs
-                ivk[live ? IV_TL + ta : 20 + ta] = tl; ivk[live ? IV_TU + ta : 20 + ta] = tu;
+                st2(ivk + (live ? IVP_T + 2 * ta : 20 + 2 * (ta & 1)), tl, tu);
                 ms += live ? w_l[i] * tl + w_h[i] * tu : T(0);
             }
         }
