@@ -56,6 +56,11 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double>
         int inst;
         const bool act = tail_pick(g, base, n, inst);
         if (__ballot(act) == 0) continue;
+        if (phase == 3 && blk == g.J - 1) {
+            // slice y = J - 1 of launch 3: the scan's forward walk (state at the start of every block), beside the final sweeps
+            block_scan_forward(g, inst, act);
+            continue;
+        }
         if (phase == 1 && blk < g.J - 1) {
             // aggregate of a block: unchanged since the last pass of this attempt if no pin code of the block changed
             const bool keep = act && g.frec && g.ts[(size_t)inst * TS_ROWS + 10] != 0.0 &&
@@ -90,7 +95,8 @@ int launch_impl(const BlockLaunch &a, const Inputs<TI> &in)
         const unsigned gx = (unsigned)a.tail_grid;
         hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)g.J), block, 0, a.stream, a.cp, g, in, 1);
         hipLaunchKernelGGL(k_block_scan_tail, dim3(gx), block, 0, a.stream, g);
-        hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)(g.J - 1)), block, 0, a.stream, a.cp, g, in, 3);
+        // (blocks 0 .. J-2: final sweeps; with fwd_in_sweep one more slice, y = J - 1: the forward walk of the boundary scan)
+        hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)(g.J - 1 + ((g.gbuf && g.fwd_in_sweep) ? 1 : 0))), block, 0, a.stream, a.cp, g, in, 3);
         return (int)hipGetLastError();
     }
     const unsigned gx = (unsigned)((g.B + 3) / 4);

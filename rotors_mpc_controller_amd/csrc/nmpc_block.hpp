@@ -68,6 +68,8 @@ struct BlockWork {
     double *xb;            // [Bp + 1][J][16]       xbar at the start of block j
     const double *frec;    // [Bp + 1][J][FR_ROWS]  records of the last pass's forward sweep (or null): a block whose pin codes did not change
                            //                       keeps its aggregate - the zero-terminal sweep depends on nothing else
+    int fwd_in_sweep;      // tail mode: the scan's forward walk (xb) runs as slice y = J - 1 of launch 3, beside the final sweeps it does not
+                           // depend on, instead of at the end of the scan kernel (round 5: 40 us of every step's critical path)
 };
 
 #if defined(__HIP_DEVICE_COMPILE__) || defined(__HIPCC__)
@@ -388,6 +390,8 @@ __device__ __forceinline__ void ldl16(double (&Au)[4][4], Ldl16 &o, double *ex, 
     }
 }
 
+__device__ __forceinline__ void block_scan_forward(const BlockWork &g, int inst, bool valid);
+
 // launch 2: the interior boundaries of one instance, last to first:  P_s = J + Psi' T Psi,  T = L (Dp^-1 + L'C L)^-1 L'
 __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int inst, bool valid)
 {
@@ -514,12 +518,26 @@ __device__ __forceinline__ void block_scan(const BlockWork &g, double *smem, int
             NMPC_UNROLL for (int jt = 0; jt < 4; jt++) bp[(it * 4 + jt) * 16] = ok ? Pe[it][jt] : __builtin_nan("");
         }
     }
-    if (g.gbuf) {
+    if (g.gbuf && !g.fwd_in_sweep) {
+        __syncthreads();                      // the tiles above were written by other lanes of this team
+        block_scan_forward(g, inst, valid);
+    }
+}
+
+// the scan's forward walk over the boundaries: xbar at the start of every block, from the aggregates and what the backward walk kept of every
+// boundary (gbuf).  Depends on the backward walk only - not on the final sweeps - so in tail mode it runs beside them (fwd_in_sweep).
+__device__ __forceinline__ void block_scan_forward(const BlockWork &g, int inst, bool valid)
+{
+    using T = double;
+    const int tid = threadIdx.x, r = ((tid >> 4) << 2) | (tid & 3);
+    const int ta = r >> 2, tc = r & 3;
+    const int rT = tc * 4 + ta;
+    const size_t winst = valid ? (size_t)inst : (size_t)g.Bp;
+    {
         // forward over the boundaries: xbar at the start of every block (stage 0: the deviation from x0 is zero, xbar = e15).
         //   xbar_e = (I + C P_e)^-1 Psi xbar_s = y - C L Le^-T De^-1 Le^-1 L' y,   y = Psi xbar_s
         // as six matrix-vector products on tiles (a vector sits in column 0 of its four tiles); every operand tile is read from
         // memory in the orientation its product needs (a transposed tile is the same 16 doubles through the swapped lane index)
-        __syncthreads();                      // the tiles above were written by other lanes of this team
         T xt[4];
         NMPC_UNROLL for (int t = 0; t < 4; t++) xt[t] = (t == 3 && ta == 3 && tc == 0) ? T(1) : T(0);
         T *xp = g.xb + winst * g.J * 16;

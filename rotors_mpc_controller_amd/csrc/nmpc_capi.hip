@@ -118,6 +118,7 @@ struct nmpc_solver {
     double *d_ts = nullptr, *d_binfo = nullptr, *tail_agg = nullptr, *tail_bnd = nullptr;
     double *tail_gbuf = nullptr, *tail_xb = nullptr, *tail_frec = nullptr;   // block-parallel forward sweep (NMPC_TAIL_FWD=0: sequential)
     int tail_fwd = 1, tail_keep = 1;          // NMPC_TAIL_KEEP=0: every pass re-aggregates every block
+    int tail_fwd_overlap = 1;                 // NMPC_TAIL_FWD_OVERLAP=0: the scan's forward walk at the end of the scan kernel (round 4) instead of beside the final sweeps
     int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
     int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
@@ -376,6 +377,7 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TAIL_CAP")) s->tail_cap = std::atoi(e);
     if (const char *e = std::getenv("NMPC_TAIL_FWD")) s->tail_fwd = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TAIL_KEEP")) s->tail_keep = std::atoi(e) != 0;
+    if (const char *e = std::getenv("NMPC_TAIL_FWD_OVERLAP")) s->tail_fwd_overlap = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -620,6 +622,7 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         bl.g.shared = c.shared != 0;
         bl.g.gbuf = s->tail_fwd ? s->tail_gbuf : nullptr; bl.g.xb = s->tail_xb;
         bl.g.frec = (s->tail_fwd && s->tail_keep) ? s->tail_frec : nullptr;
+        bl.g.fwd_in_sweep = s->tail_fwd_overlap;
         bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
         for (auto &e : bl.ev) e = nullptr;
         // the work list is compacted from step to step: every step reads one list and appends what is still in the tail to the other
