@@ -2,7 +2,7 @@
 # The measured evidence of a round in one GPU call: rocprofv3 captures (kernel trace + PMC passes) of the default workload, of the
 # plain interior point and of config 5, the bench table of DESIGN.md section 5, the full bench.py line, the block-factorisation table.
 #   gpurun --timeout 1100 -- bash tools/evidence.sh r03          (outputs under gpurun_out/; copy what is to be judged into profiles/)
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 set -e
 bash tools/rocprof_capture.sh $TAG > gpurun_out/${TAG}_capture.log 2>&1
@@ -11,6 +11,8 @@ BENCH_ARGS="--no-polish" bash tools/rocprof_capture.sh ${TAG}ipm > gpurun_out/${
 python tools/summarize_pmc.py gpurun_out/rocprof_${TAG}ipm gpurun_out/${TAG}ipm_pmc_summary.json
 BENCH_ARGS="--batch 1024 --horizon 600 --steps 4 --warmup 1" bash tools/rocprof_capture.sh ${TAG}n600 > gpurun_out/${TAG}n600_capture.log 2>&1
 python tools/summarize_pmc.py gpurun_out/rocprof_${TAG}n600 gpurun_out/${TAG}n600_pmc_summary.json
+BENCH_ARGS="--no-share" bash tools/rocprof_capture.sh ${TAG}ps > gpurun_out/${TAG}ps_capture.log 2>&1
+python tools/summarize_pmc.py gpurun_out/rocprof_${TAG}ps gpurun_out/${TAG}ps_pmc_summary.json
 echo "captures done"
 bash tools/bench_table.sh > gpurun_out/${TAG}_bench_table.txt 2>&1
 echo "bench table done"

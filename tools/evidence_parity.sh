@@ -2,7 +2,7 @@
 # The large-sample parity evidence of a round in one GPU call (outputs under gpurun_out/; copy what is to be judged into profiles/):
 #   stress sweep against the oracle (default path, plain interior point), 460-draw fuzz over what `reconfigure` can change,
 #   permutation fuzz (results must not depend on wave-mates) with the block-parallel tail forced on at short horizons.
-TAG=${1:-r04}
+TAG=${1:-r05}
 mkdir -p gpurun_out
 python tools/stress_parity.py 8192 > gpurun_out/${TAG}_stress_parity.txt 2>&1; tail -2 gpurun_out/${TAG}_stress_parity.txt
 python tools/stress_parity.py 4096 --no-polish > gpurun_out/${TAG}_stress_parity_plain_ipm.txt 2>&1; tail -2 gpurun_out/${TAG}_stress_parity_plain_ipm.txt
