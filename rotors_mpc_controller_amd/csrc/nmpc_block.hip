@@ -52,8 +52,6 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double>
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
     const int blk = blockIdx.y;
     const int n = *g.count;
-    if (g.adapt_waves > 0) tail_blocks(g.N, g.J, n, g.adapt_waves, g.J, g.M);       // the grid has the maximum's slices: the rest leave
-    if (blk >= g.J) return;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         int inst;
         const bool act = tail_pick(g, base, n, inst);
@@ -65,8 +63,7 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double>
         }
         if (phase == 1 && blk < g.J - 1) {
             // aggregate of a block: unchanged since the last pass of this attempt if no pin code of the block changed
-            // (... and the aggregates in memory were made with this step's blocks: the tail state keeps the J they belong to)
-            const bool keep = act && g.frec && g.ts[(size_t)inst * TS_ROWS + 10] == (double)g.J &&
+            const bool keep = act && g.frec && g.ts[(size_t)inst * TS_ROWS + 10] != 0.0 &&
                               g.frec[((size_t)inst * g.J + blk) * FR_ROWS] == 0.0;
             if (__ballot(act && !keep) == 0) continue;
             block_sweep<true, TI, true>(*cp, g, in, blk, smem, inst, act && !keep);
@@ -79,7 +76,6 @@ __global__ __launch_bounds__(64, 1) void k_block_scan_tail(BlockWork g)
 {
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
     const int n = *g.count;
-    if (g.adapt_waves > 0) tail_blocks(g.N, g.J, n, g.adapt_waves, g.J, g.M);
     if (blockIdx.x == 0 && threadIdx.x == 0 && g.reset_count) *g.reset_count = 0;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         int inst;

@@ -113,12 +113,11 @@ struct nmpc_solver {
     // block-parallel tail of long-horizon solves: NMPC_BLOCK_TAIL = 0 off | 1 on | unset: on from N = 160 up (measured at B = 1024: N = 120 0.24 -> 0.46 ms,
     // 150 0.72 -> 0.70, 180 1.46 -> 1.18, 250 3.33 -> 2.29, 600 17.2 -> 10.1);
     // NMPC_BLOCK_J = blocks (unset: ~0.7 sqrt(N): measured optimum of config 5, 10.0 ms at J = 16-17 against 10.3 at 21 and 10.6 at 10)
-    int block_tail = -1, block_J = 0, tail_cap = 0;   // NMPC_TAIL_CAP: passes of the first attempt the first launch performs itself (round 5: none)
+    int block_tail = -1, block_J = 0, tail_cap = 1;   // NMPC_TAIL_CAP: passes of the first attempt the first launch performs itself
     int tail_J = 0, tail_M = 0;      // blocks that hold stages, stages per block (0: the tail is not used by this handle)
     double *d_ts = nullptr, *d_binfo = nullptr, *tail_agg = nullptr, *tail_bnd = nullptr;
     double *tail_gbuf = nullptr, *tail_xb = nullptr, *tail_frec = nullptr;   // block-parallel forward sweep (NMPC_TAIL_FWD=0: sequential)
     int tail_fwd = 1, tail_keep = 1;          // NMPC_TAIL_KEEP=0: every pass re-aggregates every block
-    int tail_waves = 1024;                    // NMPC_TAIL_WAVES: a step of the tail uses as many blocks as fit this many waves for its list (0: always tail_J)
     int tail_fwd_overlap = 1;                 // NMPC_TAIL_FWD_OVERLAP=0: the scan's forward walk at the end of the scan kernel (round 4) instead of beside the final sweeps
     int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
     int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
@@ -379,7 +378,6 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TAIL_FWD")) s->tail_fwd = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TAIL_KEEP")) s->tail_keep = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TAIL_FWD_OVERLAP")) s->tail_fwd_overlap = std::atoi(e) != 0;
-    if (const char *e = std::getenv("NMPC_TAIL_WAVES")) s->tail_waves = std::max(0, std::atoi(e));
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -588,15 +586,13 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         al.cont_stride = ql.lds_stride; al.cont_lstg = ql.lstg;
         al.lds_bytes = std::max(al.lds_bytes, ql.lds_bytes);
     }
-    // passes the first launch makes itself before the tail takes over (NMPC_TAIL_CAP; default 0: none - the tail's first step holds the whole batch
-    // and cuts its horizon into as few blocks as fill the machine once, which beats 600 sequential stages on a quarter of the SIMDs)
-    const int cap = tail ? std::max(0, std::min(s->tail_cap >= 0 ? s->tail_cap : s->cfg.qp_polish_passes, s->cfg.qp_polish_passes)) : 0;
+    const int cap = tail ? std::max(1, std::min(s->tail_cap > 0 ? s->tail_cap : s->cfg.qp_polish_passes, s->cfg.qp_polish_passes)) : 0;
     if (tail) {
         // the tail's lists are reset by its last launches; a solve that returned early with an error leaves counts behind, and the next
         // one would append past list[Bp]: the three headers (count | done) start every solve at zero
         for (int *h : {s->d_wl, s->d_wl2, s->d_wl3}) HIP_TRY(s, hipMemsetAsync(h, 0, 2 * sizeof(int), st));
         HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
-        al.tail.cap = cap == 0 ? -1 : (cap < s->cfg.qp_polish_passes ? cap : 0);
+        al.tail.cap = cap < s->cfg.qp_polish_passes ? cap : 0;
         al.tail.ts = s->d_ts;
     }
     // k_team_as: the flag build (nmpc_as.hip) for what it is validated on, the default-codegen build (nmpc_qp.hip) otherwise
@@ -627,7 +623,6 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         bl.g.gbuf = s->tail_fwd ? s->tail_gbuf : nullptr; bl.g.xb = s->tail_xb;
         bl.g.frec = (s->tail_fwd && s->tail_keep) ? s->tail_frec : nullptr;
         bl.g.fwd_in_sweep = s->tail_fwd_overlap;
-        bl.g.N = s->cfg.N; bl.g.adapt_waves = s->tail_waves; tl.tail.adapt_waves = s->tail_waves;
         bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
         for (auto &e : bl.ev) e = nullptr;
         // the work list is compacted from step to step: every step reads one list and appends what is still in the tail to the other

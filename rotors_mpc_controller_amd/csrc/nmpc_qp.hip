@@ -84,8 +84,6 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     const int n = *wl.count;
-    if (tcx.adapt_waves > 0) tail_blocks(cp->N, tcx.J, n, tcx.adapt_waves, tcx.J, tcx.M);       // the blocks of this step (nmpc_team.hpp)
-    if (tcx.phase == 3 && (int)blockIdx.y >= tcx.J) return;
     const int team = (threadIdx.x >> 2) & 3;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         const int e = base + team;

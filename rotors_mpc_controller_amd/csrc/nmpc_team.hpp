@@ -57,23 +57,6 @@ enum { TS_NONE = 0, TS_IPM = 1, TS_AS = 2, TS_DONE = 3, TS_FALLBACK = 4, TS_LIST
 // [4..7] candidate command (block 0)  [8..23] state at the end of the block, natural rows (the last block's is xhat_N)
 constexpr int FR_ROWS = 24;
 
-// Blocks of a step of the block-parallel tail: as many as ONE round of the machine holds for the step's list (a block of a listed instance is a
-// team, four teams a wave, `waves` waves resident at one per SIMD), at most jmax - the latency optimum for short lists, ~0.7 sqrt(N) - and at
-// least 2.  A long list in more blocks than that runs its sweeps in several rounds of waves and pays the scan over every boundary on top
-// (config 5's first steps: 692 instances x 17 blocks = 2.9 rounds); every kernel of a step derives the same (J, M) from the list's count.
-__host__ __device__ inline void tail_blocks(int N, int jmax, int listed, int waves, int &J, int &M)
-{
-    int j = jmax;
-    if (waves > 0 && listed > 0) {
-        const int per = (listed + 3) / 4;
-        const int jj = waves / per;
-        j = jj < j ? jj : j;
-    }
-    if (j < 2) j = 2;
-    M = (N + j - 1) / j;
-    J = (N + M - 1) / M;
-}
-
 template <class T>
 struct TeamWork {
     T *tLM;

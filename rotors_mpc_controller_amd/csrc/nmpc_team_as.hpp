@@ -117,7 +117,6 @@ struct TailCtx {
     double *frec = nullptr;          // [Bp + 1][J][FR_ROWS] records of the block-parallel forward sweep (phase 3 writes, phase 2 reads), or null
     const double *xb = nullptr;      // [Bp + 1][J][16] state at the start of every block (left by the boundary scan)
     int blk = 0, M = 0;              // phase 3: this team's block, stages per block
-    int adapt_waves = 0;             // > 0: J and M follow the list's count (tail_blocks, nmpc_team.hpp); J, M above are then the maximum's
     int *nx_count = nullptr;         // the work list of the NEXT step: instances that are still in the tail after this one (the list is
     int *nx_list = nullptr;          // compacted from step to step: a wave costs the same with one live team as with four)
 };
@@ -1210,7 +1209,6 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         for (;;) {
             if (__ballot(mode == M_POL) == 0) break;
             if (tcx.cap > 0 && pass >= tcx.cap) break;       // long horizon: the block-parallel tail continues the attempt
-            if (tcx.cap < 0) break;                          // ... or makes it from its first pass (cap = -1: this launch prepares only)
             nopins_pass = pass == 0;
             as_pass();
         }
@@ -1370,8 +1368,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             tsr[0] = (T)tstate; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase; tsr[4] = mu; tsr[5] = rho;
             tsr[6] = (T)it; tsr[7] = pol_mu; tsr[8] = step_last;
             // the next pass of the same attempt re-aggregates only the blocks in which a pin code changed (nmpc_block.hip)
-            // (the J those aggregates were made with: a step whose list asks for other blocks starts over)
-            tsr[10] = (tcx.phase == 2 && tcx.frec && tstate == TS_AS) ? (T)tcx.J : T(0);
+            tsr[10] = (tcx.phase == 2 && tcx.frec && tstate == TS_AS) ? T(1) : T(0);
         }
     } else {
         // ---- phases of a wave: interior-point iterations for the teams in that mode until each has converged, failed or
@@ -1547,9 +1544,6 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             tsr[0] = (T)TS_AS; tsr[1] = (T)npol; tsr[2] = (T)pass_in_attempt; tsr[3] = gbase;
             const int slot = atomicAdd(wl.count, 1);
             wl.list[slot] = inst;
-        }
-        if (tcx.cap < 0) {        // no pass was made here: the tail's first pass starts from "all inputs free" - pin codes of every stage zero
-            for (int k = r >> 2; k < N; k += 4) tIV_own[k * IV_ROWS + 16 + (r & 3)] = T(0);
         }
         return false;
     }
