@@ -5,9 +5,10 @@
 // this file: the other three) - an INTERNAL LLVM option, so every flag build is held bit-equal to this file's build of the same kernel on
 // the GPU (NMPC_AS_NOFLAG / NMPC_QP_NOFLAG select this file; tests/test_gpu_parity.py) and is executed instruction by instruction on the CPU
 // by tools/emu with every address checked (tests/test_isa_emulation.py).  This file's builds are also what sim_num_steps > 2 runs.
-// (Round 3 wrote that the flag "miscompiles" k_team_qp<per-stage, trajectories>, after a GPU memory fault on sim_num_steps = 4 inputs.
+// (Round 3 recorded a GPU memory fault on sim_num_steps = 4 inputs of k_team_qp<per-stage, trajectories> and wrote that the flag "miscompiles" it.
 // Round 4 emulated that launch on the flag build - all 256 workgroups, 32 M instructions, no access outside a buffer, the oracle's
-// answers - and withdrew the claim: the fault came from an uncommitted working tree.  DESIGN.md section 4.2 has the examination.)
+// answers - and withdrew the claim.  The cause was NOT recovered: no committed state reproduces the fault (the binary that faulted came from a
+// working tree that was not kept).  The flag builds stay limited to sim_num_steps <= 2 (launch_qp_kind); docs/history has the examination.)
 #include <hip/hip_runtime.h>
 
 #include "nmpc_as_launch.hpp"

@@ -246,7 +246,7 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
         // independently, tile (i,j) and tile (j,i) differ by rounding, and that antisymmetric part is not
         // contracted by the recursion: it grows by rho(A)^2 per stage - harmless for the reference's vehicle
         // (rho = 1.04), a NaN after ~30 stages where the discretised open loop is violently unstable (dt = 0.1 with
-        // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The row form, the
+        // one integrator step and a small inertia: rho = 2; found by tools/dev/fuzz_parity.py).  The
         // lane kernel and the oracle carry one triangle of P only.
         NMPC_UNROLL for (int it = 0; it < 4; it++) {
             NMPC_UNROLL for (int jt = it; jt < 4; jt++) Pt[it][jt] = mfma44_na(M0[it], o.M[jt], Pn[it][jt]);      // - M0'M (negated operand: exact)

@@ -36,11 +36,10 @@ namespace nmpc {
 
 constexpr int TEAM = 16;            // lanes per instance
 constexpr int TEAMS_PER_WAVE = 4;
-constexpr int TLM_ROWS = 240;      // M (52) | L (10) | m (4) | xhat of the polish sweep (13) | pad (1) |
-                                   // tile form: Mbar^T as 4 tiles x 16 lanes (64) | L^-1 tile (16) |
-                                   // stages with pins: (B'Pbar Abar)^T unmasked (64) | (B'PB)^T (16)
+constexpr int TLM_ROWS = 240;      // per stage: [52..63] 1 / d | [66..79] xhat of the forward sweep | [80..143] Mbar^T as 4 tiles x 16 lanes |
+                                   // [144..159] L^-1 tile | [160..239] stages with pins: (B'Pbar Abar)^T unmasked (64) | (B'PB)^T (16)
 constexpr int TLM_MT = 80, TLM_Z = 144, TLM_G = 160;
-constexpr int TLM_RINV = 52;       // tile form with H_uu = L D L': the four 1 / d_a of a stage (52..63: the slot of the row form's L | m, unused there)
+constexpr int TLM_RINV = 52;       // H_uu = L D L': the four 1 / d_a of a stage (52..63)
 // TAB_ROWS (nmpc_lane.hpp): 104 (Ad rows, 8 each) + 52 (B rows) + 13 (b) + pad here; 12 tiles x 16 in the active-set kernel
 constexpr int TP_ROWS = 256;        // Riccati checkpoint of a stage: 16 tiles x 16 lanes of Pbar
 
@@ -109,14 +108,6 @@ __device__ __forceinline__ double mfma44_na(double a, double b, double c) { retu
 __device__ __forceinline__ constexpr int nat_of(int t, int e)
 {
     return t == 0 ? (e < 3 ? e : -1) : (t == 1 ? (e < 3 ? 3 + e : -1) : (t == 2 ? 6 + e : (e < 3 ? 10 + e : -1)));
-}
-
-template <class T>
-__device__ __forceinline__ T quad_sum(T x)     // over the 4 lanes 4q..4q+3 (the columns of one tile row)
-{
-    x += __shfl_xor(x, 1);
-    x += __shfl_xor(x, 2);
-    return x;
 }
 
 // Where the interior point's iterate of input a lives in a stage's row of tIV: u at a; the PAIRS (lam_l, lam_u) at IVP_L + 2a and (t_l, t_u)

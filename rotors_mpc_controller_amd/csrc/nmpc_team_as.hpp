@@ -1,24 +1,22 @@
-// nmpc_team_as.hpp -- the active-set kernel of the default FP64 path (gfx950 device code).
+// nmpc_team_as.hpp -- the solver kernels of the team mapping (gfx950 device code): ONE source, four modes.
 //
-// What it is: preparation (RTI linearisation, controller.py:419-445 staging) + the FIRST active-set attempt of
-// the QP (up to qp_polish_passes passes of "pin the active bounds, solve the remaining LQ problem with one
-// Riccati factorisation + forward sweep, check the KKT conditions of the QP in the same sweep") for four
-// instances per wave -- the tile-form sweeps of nmpc_team.hpp (v_mfma_f64_4x4x4 register tiles, lane
-// (a,c) of team b = lane 16a + 4b + c) and nothing else.  On the near-hover set 99.3 % of the instances are
-// accepted after the first pass and all of them within three; only what this attempt cannot settle (a
-// failed factorisation, a pass budget that runs out) is appended to a work list, which the general kernel
-// k_team_ipm_list (interior-point iteration + later active-set attempts) drains in a second launch.
+// team_as<MODE>:  0  preparation (RTI linearisation, controller.py:419-445 staging) + the FIRST active-set attempt of the QP (up to
+//                    qp_polish_passes passes of "pin the active bounds, solve the remaining LQ problem with one Riccati factorisation +
+//                    forward sweep, check the KKT conditions of the QP in the same sweep")                        -> k_team_as
+//                 1  the whole QP of every instance of the batch: interior-point iterations, attempts in between   -> k_team_qp
+//                 2  the same for work-list instances, continuing after a failed first attempt                     -> k_team_qp_list, and
+//                    inlined behind MODE 0 in k_team_as (team_as_kernel: a failed attempt continues on its own wave, one launch per solve)
+//                 3  one step of the block-parallel tail of long horizons (no factor sweep: nmpc_block.hpp did it)  -> k_team_tail
+// Four instances per wave: team b = lanes {16a + 4b + c}, lane (a,c) = element (a,c) of every 4 x 4 register tile, all products on
+// v_mfma_f64_4x4x4_4b.  On the near-hover set 99.3 % of the instances are accepted after the first pass and all of them within three.
 //
-// Why a kernel of its own: the general kernel holds prepare + active set + all interior-point
-// sweeps live at once -- 449 registers, 291 scalar spills, one wave per SIMD -- although its interior-point
-// half never runs on the headline workload.  This kernel carries no interior-point state, takes its
+// Why the first attempt is code of its own (MODE 0): it carries no interior-point state, takes its
 // per-lane constants into vector registers once (the 200-dword constant block is not touched inside a
 // sweep), stages nothing it can form on the fly (the cost gradients come straight from yref / x_init: no
 // qr array, no xl / ul copy) and needs 10 KB of LDS per wave, so two waves fit a SIMD.
 //
-// Arithmetic: identical to the tile-form sweeps A and B of team_ipm (same products, same order), so the
-// pass statistics and the accepted solutions are the same to rounding; the oracle restates the algorithm
-// (oracle/nmpc_oracle.c, active-set polish) and the GPU parity tests hold 1e-9 against it.
+// Arithmetic: the oracle restates the algorithm (oracle/nmpc_oracle.c: active-set polish, ocpqp_ipm) and the GPU parity tests hold
+// 1e-9 against it; pass and iteration counts are the oracle's.
 //
 // Linearisation: the state of a shooting interval is integrated by ONE lane (lane r of a team takes stage
 // k0 + r of a chunk of AS_CH stages: 4 model evaluations per stage instead of 4 replicated in 16 lanes),
@@ -146,7 +144,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     constexpr int LMR = MODE == 0 ? AS_LM_ROWS : IP_LM_ROWS;
     const int LDS_T = lds_stride;
     NMPC_PROF_BEGIN
-    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // as team_ipm
+    const int tid = threadIdx.x, team = (tid >> 2) & 3, r = ((tid >> 4) << 2) | (tid & 3);   // the MFMA block layout
     const int ta = r >> 2, tc = r & 3, j = tc;
     const int rr = r < NX ? r : NX - 1;
     const bool rowl = r < NX, cmpl = r < NU;
@@ -401,7 +399,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     const T iw_a = T(1) / (ub_a - lb_a);          // step sizes are measured against the box width
 
     // ================= sweep A: backward factorisation in tile form.
-    // Same products as the tile form of sweep A in team_ipm.  What differs is the shape of the code: a stage is
+    // The shape of the code: a stage is
     // ONE basic block (no predicated store: finished and idle teams work in a spare workspace row), P B and
     // B'P B come first so that the 4x4 Cholesky - a serial chain of ~90
     // vector instructions - runs beside the ~60 MFMAs that do not depend on it, and the first pass (nothing
@@ -537,7 +535,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     // range and start state of the forward sweep (MODE 3, block-parallel forward: one team sweeps one block; otherwise the horizon)
     int fwd_s = 0, fwd_e = N;
     const T *fwd_x = nullptr;
-    // ================= sweep B: forward solve + KKT check in tile form (team_ipm, tile form of sweep B): a stage
+    // ================= sweep B: forward solve + KKT check in tile form: a stage
     // is one basic block; operands arrive two stages ahead in two alternating register sets
     auto sweepB = [&](auto pins_tag, auto ipm_tag, auto warm_tag) {
         constexpr bool PINS = decltype(pins_tag)::value;
@@ -745,7 +743,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         if (IPMV) { if (tc == 0) { sRed[4 + ta] = rmaxB; sRed[8 + ta] = s2B; } }
     };
     // ================= interior-point iteration (kernels of MODE 1 / 2 only; generic lambdas: never instantiated in MODE 0).
-    // Same sweeps as the tile form of team_ipm (nmpc_team.hpp) in the shape of this file: a stage is one basic block, idle
+    // In the shape of the active-set sweeps above: a stage is one basic block, idle
     // and finished teams work in the spare workspace row, factors of the leading stages come from the LDS stage cache.
     // H_uu = L D L' here (unit L): the factor sweep leaves Mbar = D^-1 L^-1 X, L^-1 and the four 1 / d_a; with m0 = L^-1 g the
     // corrector's costate is pi_k = Abar' pi - Mbar' m0 and its feed-forward term is m = D^-1 m0 (column 15 of Mbar).
@@ -1125,7 +1123,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             if (ks >= vmin) ks = N - 1;
             ks = __builtin_amdgcn_readfirstlane(ks);
         }
-        // checkpoint window of this pass (see team_ipm): two stages in the first pass, the configured window after
+        // checkpoint window of this pass: two stages in the first pass, the configured window after
         wnd = pass_in_attempt == 0 ? (ckpt < 2 ? ckpt : 2) : ckpt;
         if (pol) ck_valid = (wnd < ks) ? wnd : ck_valid;
 
