@@ -142,6 +142,25 @@ def test_no_vector_instruction_sits_in_front_of_an_exec_restore_in_the_flag_buil
         assert not found, [(f[0][:50], f[2], f[3]) for f in found[:4]]
 
 
+def test_codegen_gate_of_the_build(tmp_path):
+    """tools/emu/codegen_gate.py is what `make` runs on the assembly of the flag builds before it links (round 5: the scans above moved from
+    pytest into the build).  On the shipped builds with the validated hipcc it writes mode 0 (flag builds are the default); told to expect
+    another hipcc it writes mode 1 and the reason - the library is then linked with -DNMPC_DEFAULT_NOFLAG=1 and nmpc_version() ends in
+    'codegen default'.  The loaded library's version string names its mode."""
+    import sys
+    gate = str(ROOT / "tools" / "emu" / "codegen_gate.py")
+    files = [_asm(t) for t in ("nmpc_as.s", "nmpc_qpf.s", "nmpc_blockf.s")]
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    ok, bad = tmp_path / "ok.mode", tmp_path / "bad.mode"
+    subprocess.check_call([sys.executable, gate, "--hipcc", hipcc, "--expect", "7.2", "--out", str(ok)] + files, stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, gate, "--hipcc", hipcc, "--expect", "9.9", "--out", str(bad)] + files, stdout=subprocess.DEVNULL)
+    assert ok.read_text().splitlines()[0] == "0", ok.read_text()
+    lines = bad.read_text().splitlines()
+    assert lines[0] == "1" and "validated on 9.9" in lines[1]
+    from rotors_mpc_controller_amd import _lib
+    assert _lib.library_codegen() in ("flag", "default") and ("codegen " + _lib.library_codegen()) in _lib.load().nmpc_version().decode()
+
+
 @pytest.mark.skipif(os.environ.get("NMPC_EMU_FULL") != "1", reason="NMPC_EMU_FULL=1: compiles nmpc_qp.hip with the flag (minutes); profiles/r04_emulation_*.txt holds the full runs")
 def test_the_configuration_that_faulted_in_round_3_on_the_flag_build_of_k_team_qp():
     """k_team_qp<per-stage, trajectories>, sim_num_steps = 4, qp_polish = 0, B = 256, aggressive seed 8 (gpurun_out/qp_check2.log), built WITH
