@@ -26,6 +26,8 @@ def main():
     ap.add_argument("--groups", type=int, nargs="+", default=[1, 2, 4])
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--dist", default="near_hover")
+    ap.add_argument("--offset-us", type=float, default=0.0, help="group g starts g * offset later (a spin kernel on its stream): out of phase, "
+                    "the latency-bound launches of one group run beside the throughput-bound ones of another")
     ap.add_argument("--interleave", action="store_true", help="group g takes instances g, g + G, ... instead of a contiguous slice")
     a = ap.parse_args()
     dev = torch.device("cuda", 0)
@@ -37,6 +39,12 @@ def main():
     yref = torch.from_numpy(yref_h).to(dev)
     ye = torch.from_numpy(ye_h).to(dev)
     ref_u0 = None
+    # spin kernel calibration: cycles per microsecond of torch.cuda._sleep
+    torch.cuda._sleep(1000); torch.cuda.synchronize(dev)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); torch.cuda._sleep(10_000_000); e1.record(); torch.cuda.synchronize(dev)
+    cyc_per_us = 10_000_000 / (1e3 * e0.elapsed_time(e1))
+    print(f"spin kernel: {cyc_per_us:.1f} cycles per us", flush=True)
     for G in a.groups:
         assert B % G == 0
         Bg = B // G
@@ -49,6 +57,9 @@ def main():
 
         def step():
             for g in range(G):
+                if a.offset_us > 0 and g > 0:
+                    with torch.cuda.stream(pipe.streams[g]):
+                        torch.cuda._sleep(int(g * a.offset_us * cyc_per_us))
                 pipe.submit(Bg, x0[g].data_ptr(), yref.data_ptr(), ye.data_ptr(), True, u0[g].data_ptr(), status_ptr=st[g].data_ptr(),
                             after_current_stream=False)
             pipe.synchronize()              # a step = the whole batch done (the next batch of a closed loop needs it)
@@ -65,7 +76,7 @@ def main():
         bad = sum(int(s.abs().sum()) for s in st)
         if ref_u0 is None:
             ref_u0 = full
-        print(f"groups {G}: {1e3 * el:7.3f} ms per batch of {B} (N = {N})   {B / el / 1e3:8.1f} k solves/s   status != 0: {bad}   "
+        print(f"groups {G} offset {a.offset_us:.0f} us: {1e3 * el:7.3f} ms per batch of {B} (N = {N})   {B / el / 1e3:8.1f} k solves/s   status != 0: {bad}   "
               f"max |u0 - one group| {np.abs(full - ref_u0).max():.1e}", flush=True)
         pipe.close()
 
