@@ -680,6 +680,18 @@ static int ocpqp_polish(const ocpqp *p, const double *dx0, const ricc_fact *f, d
         }
         for (int i = 0; i < (N + 1) * NX; i++) if (!(xh[i] == xh[i])) nanf = 1;
         if (nanf) break;
+        if (getenv("ORC_POLISH_TRACE")) {   /* diagnostic (tools/dev/pin_trace.py): how the pin set moves from pass to pass */
+            int npin = 0, add = 0, rel = 0, kmin = N, kmax = -1;
+            for (int k = 0; k < N; k++)
+                for (int i = 0; i < p->nu[k]; i++) {
+                    npin += pin[k][i] != 0;
+                    if (pin[k][i] == newpin[k][i]) continue;
+                    if (k < kmin) kmin = k;
+                    if (k > kmax) kmax = k;
+                    if (newpin[k][i]) add++; else rel++;
+                }
+            fprintf(stderr, "pass %2d: %4d pinned, next pass pins %3d more and releases %3d, stages %d..%d\n", pass, npin, add, rel, kmin, kmax);
+        }
         if (!changed) { ok = 1; break; }
         /* out of passes with a finished, finite pass whose pin set was not empty: the multipliers gsave / inputs uh of THIS pass seed the interior point */
         if (pass == max_pass - 1) {
