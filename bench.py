@@ -311,6 +311,7 @@ def main() -> None:
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--batch", type=int, default=4096, help="instances per GPU")
     ap.add_argument("--horizon", type=int, default=20)
+    ap.add_argument("--seed", type=int, default=None, help="seed of the x0 sample (default: 0 on one GPU, 100 + rank on several - SURVEY 8d)")
     ap.add_argument("--dtype", choices=["f64", "f32", "f32io"], default="f64",
                     help="f32io (= f32 since round 5): FP32 device buffers, FP64 arithmetic (NMPC_DTYPE_F32IO); the JSON line's dtype "
                          "stays f64 - the arithmetic - with config.device_buffers = f32")
@@ -397,7 +398,8 @@ def main() -> None:
         cfg.update(flags=cfg.flags | _lib.FLAG_CONDENSED_QP)
     solver = NmpcOcpSolver(cfg)
     hover = cfg.mass * cfg.gravity / 4.0
-    seed = 0 if world == 1 else 100 + rank                      # config 2 / config 4
+    # seed 0 = config 2 (the headline), 100 + rank = config 4 (multi-GPU); --seed 1 / 5 give the samples of configs 3 / 5
+    seed = args.seed if args.seed is not None else (0 if world == 1 else 100 + rank)
     dist_kw = NEAR_HOVER if args.dist == "near_hover" else AGGRESSIVE
     x0_h = sample_x0(B, seed, **dist_kw)
     yref_h, yref_e_h = hover_reference(N, hover)

@@ -19,10 +19,12 @@ row --mapping lane --steps 5 --warmup 1
 row --batch 1024
 row --batch 16384
 row --batch 65536 --dtype f32io
+row --batch 65536 --dtype f32io --seed 1
 row --batch 65536 --dtype f32io --no-polish --steps 20 --warmup 4
 row --batch 65536
 row --batch 65536 --no-share
 row --batch 1024 --horizon 600 --steps 5 --warmup 1
+row --batch 1024 --horizon 600 --steps 5 --warmup 1 --seed 5
 row --batch 1024 --horizon 600 --steps 5 --warmup 1 --polish-passes 8 --polish-budget 16
 row --batch 1024 --horizon 250 --steps 10 --warmup 2
 row --condensed --steps 3 --warmup 1
