@@ -381,14 +381,19 @@ static void ocpqp_free(ocpqp *p)
     orc_free(p->q); orc_free(p->r); orc_free(p->lo); orc_free(p->hi); orc_free(p->nu); orc_free(p->QN); orc_free(p->qN);
 }
 
-/* in-place lower Cholesky of an m*m row-major SPD matrix; returns 0 ok, 1 not SPD */
-/* returns 0 ok | 1 a pivot is not positive | 2 the first pivot to fail is a NaN (NaN data) */
+/* in-place lower Cholesky of an m*m row-major SPD matrix.
+ * A pivot is valid while 0 < d <= ORC_PIVOT_MAX; returns 0 ok | 1 the first invalid pivot is not positive (a failed factorisation) |
+ * 2 it is NaN or beyond ORC_PIVOT_MAX - not-a-number data: a magnitude that can no longer be squared in double precision is one
+ * (fuzz seed 11856, a warm start about a trajectory at |x| 5e10: pivot 8.9e269, then an exact 0 here and an inf - inf in the kernels'
+ * L D L' - which of the two classes came out depended on whose arithmetic overflowed first; the kernels carry the same test and the
+ * same constant, csrc/nmpc_team.hpp PIVOT_MAX) */
+#define ORC_PIVOT_MAX 1e100
 static int chol_lower(double *M, int m)
 {
     for (int j = 0; j < m; j++) {
         double d = M[j * m + j];
         for (int k = 0; k < j; k++) d -= M[j * m + k] * M[j * m + k];
-        if (!(d == d)) return 2;
+        if (!(fabs(d) <= ORC_PIVOT_MAX)) return 2;
         if (!(d > 0.0)) return 1;
         d = sqrt(d);
         M[j * m + j] = d;

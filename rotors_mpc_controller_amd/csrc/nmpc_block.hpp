@@ -79,7 +79,7 @@ struct BlockWork {
 // replaced by 1 (the constant of a value function).  ok: cleared by a pivot that is not positive.
 struct Ldl4 {
     double r0, r1, r2, r3, Y, Lt;
-    bool nan;      // a pivot was NaN
+    bool nan;      // the first failing pivot was NaN or beyond PIVOT_MAX
 };
 template <bool WANT_L>
 __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool forced_last, bool &ok)
@@ -95,8 +95,9 @@ __device__ __forceinline__ Ldl4 ldl4(double h, double *ex, int ta, int tc, bool 
     Ldl4 o;
     o.nan = false;
     auto pivot = [&](T d) -> T {
-        const bool pos = d > T(0);
-        o.nan |= ok && !(d == d);        // (the first failing pivot decides: see riccati_factor_stage)
+        const bool big = !(fabs(d) <= PIVOT_MAX);
+        const bool pos = d > T(0) && !big;
+        o.nan |= ok && big;              // (the first failing pivot decides, NaN or out of range: see riccati_factor_stage)
         ok &= pos;
         return fast_rcp(pos ? d : T(1));
     };

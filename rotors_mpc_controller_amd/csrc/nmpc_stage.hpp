@@ -193,12 +193,13 @@ __device__ __forceinline__ void riccati_factor_stage(const StageLane &L, double 
         const T h00 = Lf[lidx(0, 0)], h10 = Lf[lidx(1, 0)], h11 = Lf[lidx(1, 1)], h20 = Lf[lidx(2, 0)], h21 = Lf[lidx(2, 1)];
         const T h22 = Lf[lidx(2, 2)], h30 = Lf[lidx(3, 0)], h31 = Lf[lidx(3, 1)], h32 = Lf[lidx(3, 2)], h33 = Lf[lidx(3, 3)];
         auto pivot = [&](T d) -> T {
-            const bool pos = d > T(0);
-            // a NaN pivot counts as NaN DATA only when it is the first pivot of the sweep to fail: the sweep runs on after a pivot that is
-            // not positive (the wave's other teams need it), and what it computes for this team from then on is garbage that may well
-            // overflow to inf - inf (seeds 431 / 3043 of the fuzz: a warm start from a diverged trajectory - the oracle, which stops at
-            // the first failed pivot, reports a QP failure there, and so must this)
-            nanp |= ok && !(d == d);
+            const bool big = !(fabs(d) <= PIVOT_MAX);       // NaN, inf, or beyond what can be squared (nmpc_team.hpp)
+            const bool pos = d > T(0) && !big;
+            // a NaN / out-of-range pivot counts as NaN DATA only when it is the first pivot of the sweep to fail: the sweep runs on after a
+            // pivot that is not positive (the wave's other teams need it), and what it computes for this team from then on is garbage that
+            // may well overflow to inf - inf (seeds 431 / 3043 of the fuzz: a warm start from a diverged trajectory - the oracle, which
+            // stops at the first failed pivot, reports a QP failure there, and so must this)
+            nanp |= ok && big;
             ok &= pos;
             return fast_rcp(pos ? d : T(1));
         };

@@ -250,6 +250,30 @@ def test_late_interior_point_iterations_agree_with_the_oracle_on_the_round4_mism
         s.close()
 
 
+def test_out_of_range_pivots_are_not_a_number_data_on_both_sides():
+    """Fuzz draw 11856 (found late in round 5, profiles/r05_fuzz_parity_draws_11800_13599.txt): instance 97 ends its cold solve with status 0
+    and a trajectory at |x| 5e10 (a wild tuning on an unstable discretisation), and the warm start about THAT trajectory linearises to
+    numbers of magnitude 1e135: the first pivot of the first factorisation is 8.9e269.  The oracle's Cholesky went on to an exact zero
+    (status 4), the kernels' L D L' to inf - inf (status 1).  A pivot beyond 1e100 - a number that can no longer be squared - is not-a-number
+    data on both sides now (csrc/nmpc_team.hpp PIVOT_MAX = oracle ORC_PIVOT_MAX): status 1, and every other status of the draw agrees too."""
+    from tests.fuzz_draws import draw, oracle_config
+    over, x0, yref, ye, hov, _, _ = draw(11856)
+    s = make_solver(**over)
+    c = oracle_config(s.config, qp_polish=1)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    ref = O.solve_batch(c, x0, yref, ye, want_traj=True, nthreads=8)
+    np.testing.assert_array_equal(out["status"], ref["status"])
+    assert ref["status"][97] == 0 and np.abs(ref["x"][97]).max() > 1e10
+    out2 = s.solve_batch(x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True)
+    ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=8)
+    np.testing.assert_array_equal(out2["status"], ref2["status"])
+    assert out2["status"][97] == 1 and ref2["status"][97] == 1
+    assert np.array_equal(out2["u0"][97], np.zeros(4))
+    ok = ref2["status"] == 0
+    assert np.abs(out2["u0"][ok] - ref2["u0"][ok]).max() <= 1e-6 * max(1.0, hov)
+    s.close()
+
+
 @pytest.mark.parametrize("seed", range(8))
 def test_randomised_vehicle_tuning_and_references(seed):
     """What PositionNMPC.reconfigure can change (controller.py:63-172: mass, inertia, arm length, rotor constants ->

@@ -444,6 +444,25 @@ def test_carried_slacks_end_the_late_iterations_without_a_nan(seed, inst, warm):
     assert (un >= np.array(c.lbu) - 1e-13).all() and (un <= np.array(c.ubu) + 1e-13).all()
 
 
+def test_a_pivot_that_cannot_be_squared_is_not_a_number_data():
+    """Fuzz draw 11856, instance 97: the cold solve ends status 0 with a trajectory at |x| 5e10, the warm start about it linearises to
+    numbers of 1e135 and the first pivot of the first factorisation is 8.9e269.  Until late round 5 the Cholesky here ran on to an exact
+    zero - a failed factorisation, status 4 - while the kernels' L D L' ran into inf - inf: NaN, status 1.  A pivot is valid while
+    0 < d <= 1e100 on both sides now; the first invalid one decides, and one that is NaN or out of range is not-a-number data: status 1.
+    A pivot that is merely not positive stays a QP failure (status 4): the other failing instances of the draw."""
+    from tests.fuzz_draws import draw, oracle_config
+    over, x0, yref, ye, _, _, _ = draw(11856, materialise_refs=True)
+    c = oracle_config(over)
+    i = 97
+    ref = O.solve_batch(c, x0[i:i + 1], yref[i:i + 1], ye[i:i + 1], want_traj=True)
+    assert ref["status"][0] == 0 and np.abs(ref["x"][0]).max() > 1e10 and np.isfinite(ref["x"]).all()
+    warm = O.solve_batch(c, x0[i:i + 1], yref[i:i + 1], ye[i:i + 1], x_init=ref["x"], u_init=ref["u"], want_traj=True)
+    assert warm["status"][0] == 1 and np.array_equal(warm["u0"][0], np.zeros(NU))
+    # the draw's other failures: pivots that are not positive at sane magnitudes - QP failure, as before
+    full = O.solve_batch(c, x0, yref, ye, nthreads=8)
+    assert (full["status"] == 4).sum() == 45 and (full["status"] == 0).sum() == 212
+
+
 def test_feeding_the_bound_residuals_back_changes_nothing():
     """HPIPM feeds the residuals of the bound equations (res_d: u - lo - t_l, hi - u - t_u) into every Newton system.  With this iteration's
     feasible start and carried slacks they are zero in exact arithmetic - what they hold is rounding of size ulp(u) - so the kernels leave them
