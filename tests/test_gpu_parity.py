@@ -225,7 +225,8 @@ def test_late_interior_point_iterations_agree_with_the_oracle_on_the_round4_mism
     Seeds 431 and 3043 also hold the other mismatch of those campaigns: a warm start from a trajectory that has left the model's
     range (|x| 1e3 .. 8e5), whose first factorisation meets a pivot that is not positive - QP failure (status 4) on both sides now:
     the kernels used to report NaN (1) because the sweep that runs on after the failed pivot overflowed, the oracle because it looked
-    for NaNs in the step a failed QP leaves behind (acados returns the QP failure first).  NaN DATA is a NaN pivot on both sides."""
+    for NaNs in the step a failed QP leaves behind (acados returns the QP failure first).  NaN DATA is a first failing pivot that is NaN
+    or beyond 1e100 on both sides (two instances of seed 431's warm start: status 1 on both sides since the range test of late round 5)."""
     from tests.fuzz_draws import draw, oracle_config
     for seed in (1910, 3043, 3072, 3448, 4264, 4309, 4380, 4584, 5700, 431):
         over, x0, yref, ye, hov, _, _ = draw(seed)
@@ -239,7 +240,10 @@ def test_late_interior_point_iterations_agree_with_the_oracle_on_the_round4_mism
         ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], want_traj=True, nthreads=8)
         scale = max(1.0, hov)
         for tag, o, r, it, ps in (("cold", out, ref, it1, ps1), ("warm", out2, ref2, it2, ps2)):
-            assert (r["status"] != 1).all(), (seed, tag)
+            # no instance ends NaN - except where the DATA are out of range: a warm start about a diverged trajectory (|x| > 1e3) whose first
+            # factorisation meets a pivot beyond 1e100 is not-a-number data, status 1 on both sides (PIVOT_MAX, late round 5; seed 431)
+            nan_ok = np.abs(ref["x"]).reshape(len(x0), -1).max(1) > 1e3 if tag == "warm" else np.zeros(len(x0), bool)
+            assert (r["status"][~nan_ok] != 1).all(), (seed, tag)
             np.testing.assert_array_equal(o["status"], r["status"], err_msg=f"seed {seed} {tag}")
             np.testing.assert_array_equal(it[: len(x0)], r["iters"], err_msg=f"seed {seed} {tag}: interior-point iterations")
             if seed != 431:      # (draw 431's open loop amplifies by 2^31 over the horizon: one of its instances spends its passes differently -
