@@ -34,7 +34,7 @@ extern "C" {
 
 /* acados status numbering, consumed at controller.py:448 and mpc_controller_node:124 */
 #define NMPC_SUCCESS 0
-#define NMPC_NAN_DETECTED 1
+#define NMPC_NAN_DETECTED 1 /* not-a-number data: NaN in an input, or a linearisation whose first failing Riccati pivot is NaN or beyond 1e100 */
 #define NMPC_MAXITER 2
 #define NMPC_MINSTEP 3
 #define NMPC_QP_FAILURE 4

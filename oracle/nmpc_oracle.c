@@ -11,6 +11,7 @@
  */
 #include "nmpc_oracle.h"
 
+#include <float.h>
 #include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -1244,6 +1245,12 @@ int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
     int projected = 0, status = 0;
     orc_stats local;
     memset(&local, 0, sizeof(local));
+    /* what the caller handed in: finite or not (decides the class of a failure below) */
+    int in_nf = 0;
+    for (int i = 0; i < NX; i++) in_nf |= !(fabs(x0[i]) <= DBL_MAX) || !(fabs(yref_e[i]) <= DBL_MAX);
+    for (int i = 0; i < N * NY; i++) in_nf |= !(fabs(yref[i]) <= DBL_MAX);
+    for (int i = 0; i < (N + 1) * NX; i++) in_nf |= !(fabs(xtraj[i]) <= DBL_MAX);
+    for (int i = 0; i < N * NU; i++) in_nf |= !(fabs(utraj[i]) <= DBL_MAX);
     orc_linearize(c, xtraj, utraj, yref, yref_e, A, B, b, q, r, lo, hi, Qd, Rd, &projected);
     /* lbx_0 = ubx_0 = x0 (controller.py:414-415): delta x_0 is pinned to x0 - x_0 (U7) */
     for (int i = 0; i < NX; i++) dx0[i] = x0[i] - xtraj[i];
@@ -1260,6 +1267,13 @@ int orc_sqp_rti(const orc_config *c, const double *x0, const double *yref,
     else if (bad) status = 1;
     else if (qps == 2) status = c->qp_maxiter_status ? 2 : 0;   /* QP max-iter: tolerated in RTI or reported (U10 switch) */
     else status = 0;
+    /* The CLASS of a failure follows the inputs, not the arithmetic (late round 5): ACADOS_NAN_DETECTED (1) exactly when a value the caller
+     * handed in - x0, yref, yref_e, the linearisation trajectory - is not finite, ACADOS_QP_FAILURE (4) for every other failed solve.  On
+     * data that have left the model's range (warm starts about diverged trajectories, |x| 5e3 .. 5e10: pivots of 1e116 .. 1e269) whether a
+     * pivot came out NaN, out of range or merely not positive was decided by which sum overflowed or cancelled first - fuzz draws 431 and
+     * 11856 ended 1 on one side and 4 on the other, either way round.  The reference treats every non-zero status alike
+     * (controller.py:448-450); the kernels class their failures the same way (csrc/nmpc_ipm.hpp inputs_not_finite). */
+    if (status == 1 || status == 4) status = in_nf ? 1 : 4;
     if (status == 0) {
         for (int i = 0; i < (N + 1) * NX; i++) xtraj[i] += dx[i];
         for (int i = 0; i < N * NU; i++) utraj[i] += du[i];

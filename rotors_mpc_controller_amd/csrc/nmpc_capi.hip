@@ -43,18 +43,18 @@ __global__ __launch_bounds__(64) void k_prepare(Consts<T> c, Work<T> w, Inputs<T
 }
 
 template <class T>
-__global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Outputs<T> out, int B)
+__global__ __launch_bounds__(64) void k_ipm(Consts<T> c, Work<T> w, Inputs<T> in, Outputs<T> out, int B)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane < B) lane_ipm(c, w, out, lane);
+    if (lane < B) lane_ipm(c, w, in, out, lane);
 }
 
 // QP phase as acados configures it: partial condensing + IPM on the condensed QP (one instance per lane)
 template <class T>
-__global__ __launch_bounds__(64) void k_cond_ipm(Consts<T> c, Work<T> w, CondWork<T> cw, Outputs<T> out, int B)
+__global__ __launch_bounds__(64) void k_cond_ipm(Consts<T> c, Work<T> w, CondWork<T> cw, Inputs<T> in, Outputs<T> out, int B)
 {
     const int lane = blockIdx.x * blockDim.x + threadIdx.x;
-    if (lane < B) lane_cond_ipm(c, w, cw, out, lane);
+    if (lane < B) lane_cond_ipm(c, w, cw, in, out, lane);
 }
 
 }  // namespace
@@ -756,9 +756,9 @@ static int launch_any(nmpc_solver *s, int B, const void *x0, const void *yref, c
         cond_layout(cw, s->cfg.N, N2);
         cw.base = (T *)s->cond;
         cw.Bp = s->Bp;
-        hipLaunchKernelGGL(k_cond_ipm<T>, grid, block, 0, st, c, w, cw, out, B);
+        hipLaunchKernelGGL(k_cond_ipm<T>, grid, block, 0, st, c, w, cw, in, out, B);
     } else {
-        hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, out, B);
+        hipLaunchKernelGGL(k_ipm<T>, grid, block, 0, st, c, w, in, out, B);
     }
     HIP_TRY(s, hipGetLastError());
     if (s->timing) HIP_TRY(s, hipEventRecord(s->ev[2], st));

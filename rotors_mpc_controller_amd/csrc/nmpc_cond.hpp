@@ -70,7 +70,7 @@ inline int cond_layout(CondWork<T> &cw, int N, int N2)
 #define CWV(off) cw.base[(size_t)(off) * (size_t)cw.Bp + (size_t)lane]
 
 template <class T>
-NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<T> &cw, const Outputs<T> &out, int lane)
+NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<T> &cw, const Inputs<T> &in, const Outputs<T> &out, int lane)
 {
     const int N = c.N, Bp = w.Bp, N2 = cw.N2, nubm = cw.NUB;
     const int base_bs = N / N2, rem = N - N2 * base_bs;
@@ -480,7 +480,8 @@ NMPC_HD void lane_cond_ipm(const Consts<T> &c, const Work<T> &w, const CondWork<
         if (upd) NMPC_ST(w.xl, N * NX + i, NMPC_LD(w.xl, N * NX + i) + s);
     }
     if (bad && upd) status = 1;
-    const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
+    int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
+    if (nlp_status == 1 || nlp_status == 4) nlp_status = inputs_not_finite(in, N, lane) ? 1 : 4;     // nmpc_ipm.hpp
     w.iters[lane] = it;
     w.status[lane] = nlp_status;
     if (out.status) out.status[lane] = nlp_status;

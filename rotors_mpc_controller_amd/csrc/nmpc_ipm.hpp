@@ -35,6 +35,24 @@ struct Inputs {
     int yref_bcast;
 };
 
+// How a FAILED solve is classed (every kernel's last step; oracle orc_sqp_rti): NMPC_NAN_DETECTED (1) exactly when one of the instance's own
+// INPUTS - x0, yref, yref_e, the linearisation trajectory - is not finite, NMPC_QP_FAILURE (4) otherwise.  The class used to follow the
+// arithmetic (a NaN pivot or a NaN in the step: 1), and on data that have left the range of the model - a warm start about a diverged
+// trajectory, |x| 5e3 .. 5e10, pivots of 1e116 .. 1e269 - that made it a matter of whose sums overflowed or cancelled first: fuzz draws
+// 431 and 11856 ended 1 on one side and 4 on the other.  What the caller handed in does not depend on rounding.  (The reference treats
+// every non-zero status alike: controller.py:448-450.)
+template <class T>
+NMPC_HD bool inputs_not_finite(const Inputs<T> &in, int N, int inst)
+{
+    bool nf = false;
+    auto scan = [&](const T *p, int n) { for (int i = 0; i < n; i++) { const double v = (double)p[i]; nf |= !(fabs(v) <= 1.7976931348623157e308); } };
+    scan(in.x0 + (size_t)inst * NX, NX);
+    scan(in.yref_bcast ? in.yref : in.yref + (size_t)inst * N * NY, N * NY);
+    scan(in.yref_bcast ? in.yref_e : in.yref_e + (size_t)inst * NX, NX);
+    if (in.x_init && in.u_init) { scan(in.x_init + (size_t)inst * (N + 1) * NX, (N + 1) * NX); scan(in.u_init + (size_t)inst * N * NU, N * NU); }
+    return nf;
+}
+
 template <class T>
 struct Outputs {
     T *u0;            // [B][4]
@@ -94,7 +112,7 @@ NMPC_HD void lane_prepare(const Consts<T> &c, const Work<T> &w, const Inputs<T> 
 }
 
 template <class T>
-NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &out, int lane)
+NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Inputs<T> &in, const Outputs<T> &out, int lane)
 {
     const int N = c.N, Bp = w.Bp;
     const T nc = T(2 * NU) * T(N);
@@ -306,7 +324,8 @@ NMPC_HD void lane_ipm(const Consts<T> &c, const Work<T> &w, const Outputs<T> &ou
     NMPC_STAMP(6)
     NMPC_PROF_END(w)
     // acados RTI tolerates a QP that stopped at its iteration cap (U10)
-    const int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
+    int nlp_status = (status == 2) ? 0 : (status == 3 ? 4 : status);
+    if (nlp_status == 1 || nlp_status == 4) nlp_status = inputs_not_finite(in, N, lane) ? 1 : 4;     // the class of a failure: see inputs_not_finite
     w.iters[lane] = it;
     w.status[lane] = nlp_status;
     if (out.status) out.status[lane] = nlp_status;

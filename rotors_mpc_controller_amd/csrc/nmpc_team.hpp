@@ -103,11 +103,10 @@ __device__ __forceinline__ double mfma44(double a, double b, double c) { return 
 // (-X)'Y + C: the FP64 MFMAs take a negation per operand in their BLGP field (neg:[1,0,0]) - exact, and one v_xor_b32 per tile saved
 __device__ __forceinline__ double mfma44_na(double a, double b, double c) { return __builtin_amdgcn_mfma_f64_4x4x4f64(a, b, c, 0, 0, 1); }
 
-// A pivot of a Riccati stage is valid while 0 < d <= PIVOT_MAX.  The FIRST invalid pivot of a sweep decides how the solve ends: NaN or a
-// magnitude beyond PIVOT_MAX (numbers that can no longer be squared in double precision: a linearisation about a diverged trajectory,
-// |x| 5e10 - seed 11856 of the fuzz) is NOT-A-NUMBER DATA, status 1; a pivot that is merely not positive is a failed factorisation, status 4.
-// Same rule, same constant: chol_lower of oracle/nmpc_oracle.c.  (Without the magnitude test the class depended on which arithmetic
-// overflowed first: the oracle's Cholesky met an exact zero behind a pivot of 8.9e269, the L D L' here an inf - inf.)
+// A pivot of a Riccati stage is valid while 0 < d <= PIVOT_MAX: NaN, not positive, or a magnitude that can no longer be squared in double
+// precision (a linearisation about a diverged trajectory: pivot 8.9e269 in fuzz draw 11856) ends the factorisation instead of running
+// on into inf - inf.  Same test, same constant: chol_lower of oracle/nmpc_oracle.c.  (How a failed solve is then CLASSED - status 1 or 4 -
+// is decided by the inputs, not by which pivot failed how: inputs_not_finite, nmpc_ipm.hpp.)
 constexpr double PIVOT_MAX = 1e100;
 
 // padded state order of the tile form: p(3) _ | v(3) _ | q(4) | omega(3) 1   (index 15 is the homogeneous

@@ -1530,6 +1530,19 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             if (need_roll && t_bad) nlp_status = 1;          // NaN anywhere in the step poisons the instance
         }
     }
+    // The class of a failure (nmpc_ipm.hpp inputs_not_finite; oracle orc_sqp_rti): not-a-number data (1) exactly when one of the instance's own
+    // inputs is not finite, a QP failure (4) otherwise - whatever arithmetic event ended the solve.  A rare path: the team scans its inputs again.
+    if (__ballot(valid && (nlp_status == 1 || nlp_status == 4)) != 0) {
+        bool nf = false;
+        auto scan = [&](const TI *p, int n) { for (int i = r; i < n; i += 16) { const T v = (T)p[i]; nf |= !(fabs(v) <= T(1.7976931348623157e308)); } };
+        scan(x0p, NX); scan(yr, N * NY); scan(ye, NX);
+        if (in.x_init != nullptr && in.u_init != nullptr) {
+            scan(in.x_init + (size_t)inst * (N + 1) * NX, (N + 1) * NX);
+            scan(in.u_init + (size_t)inst * N * NU, N * NU);
+        }
+        const bool t_nf = (__ballot(nf) & team_mask) != 0;
+        if (nlp_status == 1 || nlp_status == 4) nlp_status = t_nf ? 1 : 4;
+    }
     NMPC_PROF_END(w)
     tLM = tLM_own; tIV = tIV_own;
     if (!valid) return false;

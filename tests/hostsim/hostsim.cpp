@@ -61,7 +61,7 @@ static void run(const nmpc_config &g, int B, const double *x0, const double *yre
             Outputs<T> out{ou0.data() + (size_t)c0 * NU, oxo.data() + (size_t)c0 * (N + 1) * NX, ouo.data() + (size_t)c0 * N * NU};
             for (int lane = 0; lane < n; lane++) {
                 lane_prepare(c, w, in, lane);
-                if (cond) lane_cond_ipm(c, w, cw, out, lane); else lane_ipm(c, w, out, lane);
+                if (cond) lane_cond_ipm(c, w, cw, in, out, lane); else lane_ipm(c, w, in, out, lane);
                 it[c0 + lane] = itc[lane]; st[c0 + lane] = stc[lane];
             }
         }

@@ -444,21 +444,27 @@ def test_carried_slacks_end_the_late_iterations_without_a_nan(seed, inst, warm):
     assert (un >= np.array(c.lbu) - 1e-13).all() and (un <= np.array(c.ubu) + 1e-13).all()
 
 
-def test_a_pivot_that_cannot_be_squared_is_not_a_number_data():
+def test_the_class_of_a_failed_solve_follows_its_inputs():
     """Fuzz draw 11856, instance 97: the cold solve ends status 0 with a trajectory at |x| 5e10, the warm start about it linearises to
-    numbers of 1e135 and the first pivot of the first factorisation is 8.9e269.  Until late round 5 the Cholesky here ran on to an exact
-    zero - a failed factorisation, status 4 - while the kernels' L D L' ran into inf - inf: NaN, status 1.  A pivot is valid while
-    0 < d <= 1e100 on both sides now; the first invalid one decides, and one that is NaN or out of range is not-a-number data: status 1.
-    A pivot that is merely not positive stays a QP failure (status 4): the other failing instances of the draw."""
+    numbers of 1e135 and the first pivot of the first factorisation is 8.9e269 (beyond ORC_PIVOT_MAX: the factorisation ends there).  Which
+    arithmetic event ends a solve on such data - a NaN, an overflow, an exact zero - is decided by rounding and differed between this
+    Cholesky and the kernels' L D L' (draws 11856 and 431, either way round), so the class of a failure follows the inputs: status 1
+    exactly when a value handed in is not finite, status 4 otherwise."""
     from tests.fuzz_draws import draw, oracle_config
     over, x0, yref, ye, _, _, _ = draw(11856, materialise_refs=True)
     c = oracle_config(over)
     i = 97
-    ref = O.solve_batch(c, x0[i:i + 1], yref[i:i + 1], ye[i:i + 1], want_traj=True)
+    one = lambda a: a[i:i + 1]
+    ref = O.solve_batch(c, one(x0), one(yref), one(ye), want_traj=True)
     assert ref["status"][0] == 0 and np.abs(ref["x"][0]).max() > 1e10 and np.isfinite(ref["x"]).all()
-    warm = O.solve_batch(c, x0[i:i + 1], yref[i:i + 1], ye[i:i + 1], x_init=ref["x"], u_init=ref["u"], want_traj=True)
-    assert warm["status"][0] == 1 and np.array_equal(warm["u0"][0], np.zeros(NU))
-    # the draw's other failures: pivots that are not positive at sane magnitudes - QP failure, as before
+    warm = O.solve_batch(c, one(x0), one(yref), one(ye), x_init=ref["x"], u_init=ref["u"], want_traj=True)
+    assert warm["status"][0] == 4 and np.array_equal(warm["u0"][0], np.zeros(NU))
+    for field in ("x0", "yref", "ye", "xi", "ui"):
+        a = dict(x0=one(x0).copy(), yref=one(yref).copy(), ye=one(ye).copy(), xi=ref["x"].copy(), ui=ref["u"].copy())
+        a[field].reshape(-1)[a[field].size // 2] = np.inf if field == "yref" else np.nan
+        r = O.solve_batch(c, a["x0"], a["yref"], a["ye"], x_init=a["xi"], u_init=a["ui"])
+        assert r["status"][0] == 1, field
+    # the draw's cold solves: 45 failed factorisations at finite inputs - QP failures
     full = O.solve_batch(c, x0, yref, ye, nthreads=8)
     assert (full["status"] == 4).sum() == 45 and (full["status"] == 0).sum() == 212
 
