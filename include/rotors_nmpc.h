@@ -34,10 +34,10 @@ extern "C" {
 
 /* acados status numbering, consumed at controller.py:448 and mpc_controller_node:124 */
 #define NMPC_SUCCESS 0
-#define NMPC_NAN_DETECTED 1 /* not-a-number data: NaN in an input, or a linearisation whose first failing Riccati pivot is NaN or beyond 1e100 */
+#define NMPC_NAN_DETECTED 1 /* a solve that failed AND an input of the instance (x0, yref, yref_e, x_init, u_init) is not finite */
 #define NMPC_MAXITER 2
 #define NMPC_MINSTEP 3
-#define NMPC_QP_FAILURE 4
+#define NMPC_QP_FAILURE 4   /* every other failed solve (min step, failed or untrusted factorisation, NaN from finite inputs) */
 
 /* argument errors of set/get/solve_batch are negative and leave a message in nmpc_last_error */
 #define NMPC_EARG (-1)

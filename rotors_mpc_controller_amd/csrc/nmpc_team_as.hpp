@@ -1145,12 +1145,12 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         const bool trip = pol && c.growth_max > T(0) && gt > c.growth_max * gbase;
         bool pol_fail = false;
         if (pol && !ok) {
-            // A NaN pivot with nothing pinned (first pass) means NaN data: status 1.  In a later pass it can be the pinned
-            // recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per
-            // stage there - and is one more way for the attempt to fail: the interior point iteration takes over, as in the
-            // oracle (ocpqp_polish breaks out of a pass that produced a NaN)
-            if (nanp && nopins_pass) { status = 1; mode = M_DONE; }
-            else pol_fail = true;                       // give up this attempt
+            // An invalid pivot (NaN, out of range, not positive) is one more way for the attempt to fail: the interior-point iteration takes
+            // over, as in the oracle (ocpqp_polish breaks out of such a pass) - with NaN data it fails at its first factorisation, and the
+            // end of the kernel classes the failure by the inputs.  (Until late round 5 a NaN pivot of the FIRST pass ended the solve here
+            // with status 1 and no iteration, where the oracle counts the one the interior point attempts: draw 431.)  In a later pass it can
+            // be the pinned recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per stage
+            pol_fail = true;                            // give up this attempt
         }
         if (trip) { pol_fail = true; tripped = true; }  // not accurate enough to be accepted (see qp_growth_max): the attempt fails
         pol2 = mode == M_POL;
