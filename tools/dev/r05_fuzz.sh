@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the three parity campaigns of rounds 3-4 re-run on the build that carries its slacks (5160 draws: seeds 0-459, 1000-2199, 3000-6499),
 # in chunks that fit one GPU call each:  gpurun -- bash tools/dev/r05_fuzz.sh <a|b|c|d>
+# (g): the two other warm starts of the fuzzer - an arbitrary, dynamically inconsistent linearisation trajectory; each side's own result - on new seeds
 # (e), (f): late in the round, two more campaigns on seeds no build has seen (10000-13599)
 # plus (d) a campaign on seeds no build has seen (7000-7999) and the short fuzzers of the other kinds
 mkdir -p gpurun_out
@@ -17,4 +18,6 @@ case "$1" in
      timeout -k 10 100 python tools/dev/fuzz_parity.py 60 8200 --cond > gpurun_out/r05_fuzz_condensed_kernel_draws_8200_8259.txt 2>&1; tail -1 gpurun_out/r05_fuzz_condensed_kernel_draws_8200_8259.txt ;;
   e) timeout -k 10 1080 python tools/dev/fuzz_parity.py 1800 10000 > gpurun_out/r05_fuzz_parity_draws_10000_11799.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_10000_11799.txt ;;
   f) timeout -k 10 1080 python tools/dev/fuzz_parity.py 1800 11800 > gpurun_out/r05_fuzz_parity_draws_11800_13599.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_11800_13599.txt ;;
+  g) timeout -k 10 520 python tools/dev/fuzz_parity.py 700 20000 --random-init > gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt
+     timeout -k 10 520 python tools/dev/fuzz_parity.py 700 21000 --chained > gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt ;;
 esac
