@@ -825,10 +825,13 @@ static void ipm_true_residuals(const ocpqp *p, const double *dx0, double **u, do
 }
 
 /* attempt policy of the active-set passes where the configuration leaves it at 0: the library's rule (csrc/nmpc_consts.hpp,
- * resolve_polish_policy, which has the measurement) - 8 passes per attempt and 16 in total below N = 160, ONE attempt of 16 from there up */
+ * resolve_polish_policy, which has the measurements) - 8 passes per attempt and 16 in total below N = 160, ONE attempt of N / 16 passes
+ * (16 .. 32) from there up */
 static void orc_polish_policy(const orc_config *c, int N, int *passes, int *budget)
 {
-    *passes = c->qp_polish_passes > 0 ? c->qp_polish_passes : (N >= 160 ? 16 : 8);
+    int lp = N / 16;                       /* one attempt of N / 16 passes, at least 16, at most 32, from N = 160 up */
+    lp = lp < 16 ? 16 : (lp > 32 ? 32 : lp);
+    *passes = c->qp_polish_passes > 0 ? c->qp_polish_passes : (N >= 160 ? lp : 8);
     *budget = c->qp_polish_budget > 0 ? c->qp_polish_budget : (N >= 160 ? (*passes > 16 ? *passes : 16) : 2 * *passes);
 }
 

@@ -10,15 +10,24 @@
 namespace nmpc {
 
 // Attempt policy of the active-set passes where nmpc_config leaves it at 0 (the default): 8 passes per attempt, 16 in total below N = 160;
-// from N = 160 up ONE attempt of 16 passes.  Why the long horizon differs (round 5, measured on config 5: N = 600, B = 1024, near hover):
+// from N = 160 up ONE attempt of 16-32 passes.  Why the long horizon differs (round 5, measured on config 5: N = 600, B = 1024, near hover):
 // an interior-point iteration between two attempts is three sequential 600-stage solves (0.9 ms of a 7.3 ms solve) and re-derives the
 // active set the passes were converging to anyway - with one attempt of 16 every instance of the sample is accepted without one (14 passes
 // at most instead of 8 + 1 iteration + 5), and the commands are the same bits (an accepted pass is the exact solution of the same pinned
 // problem).  On short horizons the split schedule stays: there the iteration is cheap and caps what a wave's slowest team costs its mates.
+// How long that one attempt may be grows with the horizon: N / 16 passes, at least 16, at most 32 (N = 250: 16, N = 600: 32).  The pins of
+// a long horizon are found by creeping (section 4.5 of DESIGN.md: the saturated stretch at the end of the horizon is entered from its far end,
+// a few stages per pass), so the pass count scales with N: at N = 600 the near-hover samples need 13-14 passes at most on ten of twelve
+// seeds but 20 and 23 on seeds 1 and 5 (ONE instance of 1 024 each), the aggressive sample 28; at N = 250 nothing needs more than 11.  An
+// instance that runs out of passes leaves the block-parallel tail for the sequential interior point - 19-20 iterations over 600 stages,
+// 25 ms where the whole batch takes 6: with 16 passes config 5 on the SURVEY's own sample (seed 5) took 31.3 ms, with 32 it takes 8.6
+// (seed 1: 32.7 -> 7.9; aggressive: 34.8 -> 11.3); the sixteen extra steps cost a batch that does not need them 0.2 ms (seed 0: 5.84 -> 6.04;
+// profiles/r05p_config5_budget.txt).
 // The oracle applies the same rule (oracle/nmpc_oracle.c: orc_polish_policy).
+inline int long_horizon_passes(int N) { const int p = N / 16; return p < 16 ? 16 : (p > 32 ? 32 : p); }
 inline void resolve_polish_policy(int N, int &passes, int &budget)
 {
-    if (passes <= 0) passes = N >= 160 ? 16 : 8;
+    if (passes <= 0) passes = N >= 160 ? long_horizon_passes(N) : 8;
     if (budget <= 0) budget = N >= 160 ? (passes > 16 ? passes : 16) : 2 * passes;
 }
 

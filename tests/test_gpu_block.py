@@ -117,7 +117,7 @@ TWO_ATTEMPTS = dict(qp_polish_passes=8, qp_polish_budget=16)     # the schedule 
 
 @pytest.mark.parametrize("N,B,dist,J,over", [
     (600, 1024, NEAR_HOVER, 0, TWO_ATTEMPTS),                                # config 5 under the two-attempt schedule: ~100 instances take the iteration
-    (600, 1024, NEAR_HOVER, 0, {}),                                          # config 5 as shipped: ONE attempt of 16 passes from N = 160 up (round 5)
+    (600, 1024, NEAR_HOVER, 0, {}),                                          # config 5 as shipped: ONE attempt of N / 16 = 32 passes (from N = 160 up, round 5)
     (600, 256, NEAR_HOVER, 12, TWO_ATTEMPTS),
     (57, 512, WILD, 6, {}),                                                  # short horizon, tail forced on: most of the batch passes through it
     (20, 512, WILD, 4, dict(qp_polish_passes=3, qp_polish_budget=6)),        # tight attempts: many instances leave the tail for the fallback list
@@ -138,9 +138,9 @@ def test_block_parallel_tail_gives_the_results_of_the_sequential_work_list(N, B,
     if over.get("qp_polish_passes", 8) < 8:
         assert fb > 0                                            # ... and with tight attempts some to the fallback list
     if one_attempt:
-        # more than eight passes in ONE attempt and no iteration in between; of the 1024 instances one runs out of its 16 passes (it does under
-        # the two-attempt schedule too) and is finished by the interior point from the fallback list
-        assert np.abs(psb).max() > 8 and int((itb > 0).sum()) <= 1
+        # ONE attempt of N / 16 passes (32 at N = 600) and no iteration in between: the one instance of the 1024 that ran out of 16 passes - and
+        # then cost the batch 25 ms of sequential interior point from the fallback list - is accepted after 23 (late round 5)
+        assert np.abs(psb).max() > 16 and int((itb > 0).sum()) == 0
     np.testing.assert_array_equal(a["status"], b["status"])
     np.testing.assert_array_equal(ita, itb)
     np.testing.assert_array_equal(psa, psb)
