@@ -52,37 +52,9 @@ __global__ __launch_bounds__(64, 1) void k_block_sweep_tail(const Consts<double>
     __shared__ __attribute__((aligned(16))) double smem[4 * BLK_LDS];
     const int blk = blockIdx.y;
     const int n = *g.count;
-    const bool fused = phase == 1 && g.quad_cnt != nullptr;
-    // (fused with the scan: the count of the NEXT step's list is zeroed here, where the separate scan launch did it - nobody reads or appends to it now)
-    if (fused && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0 && g.reset_count) *g.reset_count = 0;
     for (int base = blockIdx.x * 4; base < n; base += gridDim.x * 4) {
         int inst;
         const bool act = tail_pick(g, base, n, inst);
-        if (fused) {
-            // Launch 1 fused with the boundary scan: the J block waves of these four list entries count themselves off after their part (an
-            // aggregate, the last block's ordinary sweep, or nothing: a kept aggregate); the last one to arrive has every aggregate of the
-            // quad in front of it (release fence / count / acquire fence at device scope) and walks the boundaries - a quad's scan no
-            // longer waits for the slowest quad of the batch, and a step is one launch shorter.  The counter is left at zero.
-            if (__ballot(act) != 0) {
-                if (blk < g.J - 1) {
-                    const bool keep = act && g.frec && g.ts[(size_t)inst * TS_ROWS + 10] != 0.0 &&
-                                      g.frec[((size_t)inst * g.J + blk) * FR_ROWS] == 0.0;
-                    if (__ballot(act && !keep) != 0) { block_sweep<true, TI, true>(*cp, g, in, blk, smem, inst, act && !keep); __syncthreads(); }
-                } else {
-                    block_sweep<false, TI, true>(*cp, g, in, blk, smem, inst, act);
-                    __syncthreads();
-                }
-            }
-            __threadfence();
-            int prev = 0;
-            if (threadIdx.x == 0) prev = atomicAdd(&g.quad_cnt[base >> 2], 1);
-            prev = __builtin_amdgcn_readfirstlane(prev);
-            if (prev != (int)gridDim.y - 1) continue;
-            if (threadIdx.x == 0) g.quad_cnt[base >> 2] = 0;
-            __threadfence();
-            if (__ballot(act) != 0) { block_scan(g, smem, inst, act); __syncthreads(); }
-            continue;
-        }
         if (__ballot(act) == 0) continue;
         if (phase == 3 && blk == g.J - 1) {
             // slice y = J - 1 of launch 3: the scan's forward walk (state at the start of every block), beside the final sweeps
@@ -122,7 +94,7 @@ int launch_impl(const BlockLaunch &a, const Inputs<TI> &in)
     if (a.tail_grid > 0) {
         const unsigned gx = (unsigned)a.tail_grid;
         hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)g.J), block, 0, a.stream, a.cp, g, in, 1);
-        if (!g.quad_cnt) hipLaunchKernelGGL(k_block_scan_tail, dim3(gx), block, 0, a.stream, g);      // (fused: the last block wave of a quad scans)
+        hipLaunchKernelGGL(k_block_scan_tail, dim3(gx), block, 0, a.stream, g);
         // (blocks 0 .. J-2: final sweeps; with fwd_in_sweep one more slice, y = J - 1: the forward walk of the boundary scan)
         hipLaunchKernelGGL((k_block_sweep_tail<TI>), dim3(gx, (unsigned)(g.J - 1 + ((g.gbuf && g.fwd_in_sweep) ? 1 : 0))), block, 0, a.stream, a.cp, g, in, 3);
         return (int)hipGetLastError();

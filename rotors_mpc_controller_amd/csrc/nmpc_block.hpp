@@ -68,8 +68,6 @@ struct BlockWork {
     double *xb;            // [Bp + 1][J][16]       xbar at the start of block j
     const double *frec;    // [Bp + 1][J][FR_ROWS]  records of the last pass's forward sweep (or null): a block whose pin codes did not change
                            //                       keeps its aggregate - the zero-terminal sweep depends on nothing else
-    int *quad_cnt;         // tail mode, launch 1 fused with the scan (late round 5): one counter per four list entries; the LAST of the J block
-                           // waves of a quad to finish its aggregate goes on to the boundary scan of that quad - no separate launch (null: separate)
     int fwd_in_sweep;      // tail mode: the scan's forward walk (xb) runs as slice y = J - 1 of launch 3, beside the final sweeps it does not
                            // depend on, instead of at the end of the scan kernel (round 5: 40 us of every step's critical path)
 };

@@ -121,8 +121,6 @@ struct nmpc_solver {
     int tail_fwd_overlap = 1;                 // NMPC_TAIL_FWD_OVERLAP=0: the scan's forward walk at the end of the scan kernel (round 4) instead of beside the final sweeps
     int *d_wl2 = nullptr;            // fallback list of the tail: count | done | list [Bp]
     int *d_wl3 = nullptr;            // second work list of the tail (the list is compacted from step to step, alternating with d_wl)
-    int *d_qc = nullptr;             // quad counters of the fused tail launches: [0, nq) launch 1 + scan, [nq, 2 nq) forward blocks + decision (nq = Bp / 4 + 1)
-    int tail_fuse = 1;               // NMPC_TAIL_FUSE=0: the scan and the decision as launches of their own (five launches per step instead of three)
     int team_occ = 0;   // 0 = default; NMPC_TEAM_OCC=1|2 picks the register budget variant
     int team_tpw = 0;   // 0 = choose from the batch size; NMPC_TEAM_TPW=1|2|4 overrides (experiments)
 
@@ -380,7 +378,6 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
     if (const char *e = std::getenv("NMPC_TAIL_FWD")) s->tail_fwd = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TAIL_KEEP")) s->tail_keep = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TAIL_FWD_OVERLAP")) s->tail_fwd_overlap = std::atoi(e) != 0;
-    if (const char *e = std::getenv("NMPC_TAIL_FUSE")) s->tail_fuse = std::atoi(e) != 0;
     if (const char *e = std::getenv("NMPC_TEAM_TPW")) {
         const int v = std::atoi(e);
         if (v == 1 || v == 2 || v == 4) s->team_tpw = v;
@@ -412,13 +409,11 @@ nmpc_solver *nmpc_create(const nmpc_config *cfg)
                       gmalloc(s, (void **)&s->tail_bnd, Bw * (J + 1) * BLK_MAT * sizeof(double)) == hipSuccess &&
                       gmalloc(s, (void **)&s->d_wl2, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                       gmalloc(s, (void **)&s->d_wl3, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
-                      gmalloc(s, (void **)&s->d_qc, 2 * ((size_t)s->Bp / 4 + 1) * sizeof(int)) == hipSuccess &&
                       gmalloc(s, (void **)&s->tail_gbuf, Bw * J * BLK_GB * sizeof(double)) == hipSuccess &&
                       gmalloc(s, (void **)&s->tail_xb, Bw * J * 16 * sizeof(double)) == hipSuccess &&
                       gmalloc(s, (void **)&s->tail_frec, Bw * J * FR_ROWS * sizeof(double)) == hipSuccess;
             ok = ok && hipMemset(s->d_wl2, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_wl3, 0, ((size_t)s->Bp + 2) * sizeof(int)) == hipSuccess &&
-                 hipMemset(s->d_qc, 0, 2 * ((size_t)s->Bp / 4 + 1) * sizeof(int)) == hipSuccess &&
                  hipMemset(s->d_ts, 0, Bw * TS_ROWS * sizeof(double)) == hipSuccess &&
                  hipMemset(s->d_binfo, 0, Bw * J * 2 * sizeof(double)) == hipSuccess;
             if (!ok) {
@@ -454,7 +449,7 @@ void nmpc_destroy(nmpc_solver *s)
     for (void *p : ptrs)
         if (p) (void)gfree(s, p);
     for (void *p : {(void *)s->blk_agg, (void *)s->blk_bnd, (void *)s->blk_chk, (void *)s->blk_fac, (void *)s->d_ts, (void *)s->d_binfo,
-                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3, (void *)s->d_qc, (void *)s->tail_gbuf, (void *)s->tail_xb,
+                    (void *)s->tail_agg, (void *)s->tail_bnd, (void *)s->d_wl2, (void *)s->d_wl3, (void *)s->tail_gbuf, (void *)s->tail_xb,
                     (void *)s->tail_frec})
         if (p) (void)gfree(s, p);
     for (auto &e : s->blk_ev)
@@ -597,7 +592,6 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         // one would append past list[Bp]: the three headers (count | done) start every solve at zero
         for (int *h : {s->d_wl, s->d_wl2, s->d_wl3}) HIP_TRY(s, hipMemsetAsync(h, 0, 2 * sizeof(int), st));
         HIP_TRY(s, hipMemsetAsync(s->d_ts, 0, ((size_t)s->Bp + 1) * TS_ROWS * sizeof(double), st));
-        HIP_TRY(s, hipMemsetAsync(s->d_qc, 0, 2 * ((size_t)s->Bp / 4 + 1) * sizeof(int), st));     // (left at zero by every step; a solve that ended in an error may not have)
         al.tail.cap = cap < s->cfg.qp_polish_passes ? cap : 0;
         al.tail.ts = s->d_ts;
     }
@@ -629,11 +623,6 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
         bl.g.gbuf = s->tail_fwd ? s->tail_gbuf : nullptr; bl.g.xb = s->tail_xb;
         bl.g.frec = (s->tail_fwd && s->tail_keep) ? s->tail_frec : nullptr;
         bl.g.fwd_in_sweep = s->tail_fwd_overlap;
-        // fused launches (late round 5): the last block wave of a quad to finish launch 1 runs the quad's boundary scan, the last one to finish the
-        // forward blocks runs its decision - three launches per step instead of five, and neither waits for the slowest quad of the batch
-        const bool fuse = s->tail_fuse && s->tail_fwd;
-        const size_t nq = (size_t)s->Bp / 4 + 1;
-        bl.g.quad_cnt = fuse ? s->d_qc : nullptr;
         bl.stream = st; bl.timing = false; bl.tail_grid = ngrid;
         for (auto &e : bl.ev) e = nullptr;
         // the work list is compacted from step to step: every step reads one list and appends what is still in the tail to the other
@@ -655,11 +644,8 @@ static int launch_split(nmpc_solver *s, const Consts<double> &c, const Work<doub
                 // forward sweep of the pass: the blocks of every instance at the same time (phase 3), then the decision (phase 2)
                 tl.tail.frec = s->tail_frec; tl.tail.xb = s->tail_xb; tl.tail.M = s->tail_M;
                 tl.tail.phase = 3;
-                tl.tail.quad_cnt = fuse ? s->d_qc + nq : nullptr;
                 HIP_TRY(s, (hipError_t)launch_qp_kind(s, tl, in, out));
                 tl.tail.phase = 2;
-                tl.tail.quad_cnt = nullptr;
-                if (fuse) { cur ^= 1; return 0; }               // the decision ran inside the forward launch
             }
             HIP_TRY(s, (hipError_t)launch_qp_kind(s, tl, in, out));
             cur ^= 1;

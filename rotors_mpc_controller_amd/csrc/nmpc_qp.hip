@@ -96,39 +96,12 @@ __global__ __launch_bounds__(64, 1) void k_team_tail(const Consts<double> *__res
             const int slot = atomicAdd(tcx.nx_count, 1);
             tcx.nx_list[slot] = inst;
         }
-        const bool fused = tcx.phase == 3 && tcx.quad_cnt != nullptr;
-        if (__ballot(act) == 0 && !fused) continue;
+        if (__ballot(act) == 0) continue;
         TailCtx tc2 = tcx;
         tc2.blk = blockIdx.y;                  // (phase 3: one block of the horizon per team; the grid's y dimension is 1 otherwise)
-        if (__ballot(act) != 0) {
-            team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
-                                               act ? inst : -1, tc2);
-            __syncthreads();
-        }
-        if (fused) {
-            // Phase 3 fused with the decision: the J block waves of these four list entries count themselves off; the last one to arrive has
-            // every block's records in front of it (release fence before the count, acquire fence after it, device scope: the waves sit on
-            // different XCDs) and runs phase 2 for the quad - the decision no longer waits for the slowest quad of the batch, and a step is
-            // one launch shorter.  The counter is left at zero for the next step.
-            __threadfence();
-            int prev = 0;
-            if (threadIdx.x == 0) prev = atomicAdd(&tcx.quad_cnt[base >> 2], 1);
-            prev = __builtin_amdgcn_readfirstlane(prev);
-            if (prev != (int)gridDim.y - 1) continue;
-            if (threadIdx.x == 0) tcx.quad_cnt[base >> 2] = 0;
-            __threadfence();
-            const int st2 = inst >= 0 ? (int)tcx.ts[(size_t)inst * TS_ROWS] : (int)TS_NONE;
-            const bool act2 = inst >= 0 && st2 == TS_AS;
-            if (inst >= 0 && !act2 && (st2 == TS_IPM || st2 == TS_AS) && (threadIdx.x & 0x33) == 0) {
-                const int slot = atomicAdd(tcx.nx_count, 1);
-                tcx.nx_list[slot] = inst;
-            }
-            if (__ballot(act2) == 0) continue;
-            tc2.phase = 2; tc2.blk = 0;
-            team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
-                                               act2 ? inst : -1, tc2);
-            __syncthreads();
-        }
+        team_as<SHARED, TRAJ, true, TI, 3>(*cp, w, in, out, tw, wl, B, 4, reinterpret_cast<double *>(smem_raw), lds_stride, 0, lm_off,
+                                           act ? inst : -1, tc2);
+        __syncthreads();
     }
 }
 

@@ -117,8 +117,6 @@ struct TailCtx {
     int blk = 0, M = 0;              // phase 3: this team's block, stages per block
     int *nx_count = nullptr;         // the work list of the NEXT step: instances that are still in the tail after this one (the list is
     int *nx_list = nullptr;          // compacted from step to step: a wave costs the same with one live team as with four)
-    int *quad_cnt = nullptr;         // phase 3, fused with the decision (late round 5): one counter per four list entries; the LAST of the J block
-                                     // waves of a quad to finish its forward sweep goes on to phase 2 for that quad - no separate launch
 };
 
 // MODE 0: preparation + the FIRST active-set attempt, give-ups to the work list (k_team_as: the first launch of the default path)
