@@ -12,17 +12,23 @@ WILD = dict(sigma_p=3.0, sigma_v=3.0, max_angle_deg=90.0, sigma_w=3.0)
 DISTS = (NEAR_HOVER, AGGRESSIVE, WILD)
 
 
-def draw(seed: int, materialise_refs: bool = False):
+def draw(seed: int, materialise_refs: bool = False, horizons=None, max_batch=None):
     """Returns (over, x0, yref, yref_e, hover_thrust, dist_index): `over` are the nmpc_config overrides of the draw (the
     random stream is consumed in the order tools/dev/fuzz_parity.py always used, so seeds name the same draws as in
-    profiles/r02f_fuzz_*).  materialise_refs: per-instance [B,N,17] references even where the draw broadcasts one."""
+    profiles/r02f_fuzz_*).  materialise_refs: per-instance [B,N,17] references even where the draw broadcasts one.
+    horizons / max_batch (late round 5, tools/dev/fuzz_parity.py --long): the horizon drawn from this list instead - the block-parallel
+    tail of N >= 160 on random vehicles - and the batch capped (the oracle's time); the default draws are unchanged."""
     rng = np.random.default_rng(7000 + seed)
     N = int(rng.choice([1, 2, 3, 5, 8, 9, 16, 20, 24, 31, 40, 57]))
+    if horizons is not None:
+        N = int(horizons[seed % len(horizons)])
     mass = float(rng.uniform(0.3, 4.0))
     arm = float(rng.uniform(0.08, 0.5))
     km = float(rng.uniform(0.003, 0.04))
     hov = mass * 9.81 / 4.0
     B = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 130, 257, 511]))
+    if max_batch is not None:
+        B = min(B, int(max_batch))
     over = dict(N=N, dt=float(rng.choice([0.01, 0.02, 0.05, 0.08, 0.1])), mass=mass,
                 inertia=[float(v) for v in rng.uniform(0.002, 0.04, 3) * mass],
                 rotor_x=[arm, 0.0, -arm, 0.0], rotor_y=[0.0, arm, 0.0, -arm], rotor_z=[-km, km, -km, km],

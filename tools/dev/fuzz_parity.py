@@ -17,6 +17,8 @@ from tests.fuzz_draws import draw, oracle_config  # noqa: E402
 
 n_draws = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+# --long: horizons of the block-parallel tail (N >= 160) on the random vehicles, batches capped for the oracle's sake
+LONG = dict(horizons=[160, 200, 256, 320, 400, 600], max_batch=65) if "--long" in sys.argv else {}
 MAPPING = "lane" if "--lane" in sys.argv else ("cond" if "--cond" in sys.argv else "team")     # the fidelity kernels: plain IPM on both sides
 # Tolerances (relative to max(1, hover thrust)).  An instance that ends on an ACCEPTED active-set solution on both sides is the
 # exact QP solution to rounding times the conditioning of the pinned problem: 1e-8 (weights spread over four decades; the
@@ -28,7 +30,7 @@ worst_as = worst_ipm = 0.0
 bad = 0
 bad_status = 0        # draws with a status that differs from the oracle's on some instance: since round 5 (slacks as iterates on both sides) none is tolerated
 for seed in range(first, first + n_draws):
-    over, x0, yref, ye, hov, di, rng = draw(seed)
+    over, x0, yref, ye, hov, di, rng = draw(seed, **LONG)
     N, B = over["N"], over["max_batch"]
     if MAPPING != "team":
         over.pop("qp_polish_ckpt")

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the three parity campaigns of rounds 3-4 re-run on the build that carries its slacks (5160 draws: seeds 0-459, 1000-2199, 3000-6499),
 # in chunks that fit one GPU call each:  gpurun -- bash tools/dev/r05_fuzz.sh <a|b|c|d>
+# (h): horizons 160 .. 600 on the random vehicles (the block-parallel tail; batches <= 65)
 # (g): the two other warm starts of the fuzzer - an arbitrary, dynamically inconsistent linearisation trajectory; each side's own result - on new seeds
 # (e), (f): late in the round, two more campaigns on seeds no build has seen (10000-13599)
 # plus (d) a campaign on seeds no build has seen (7000-7999) and the short fuzzers of the other kinds
@@ -20,4 +21,5 @@ case "$1" in
   f) timeout -k 10 1080 python tools/dev/fuzz_parity.py 1800 11800 > gpurun_out/r05_fuzz_parity_draws_11800_13599.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_11800_13599.txt ;;
   g) timeout -k 10 520 python tools/dev/fuzz_parity.py 700 20000 --random-init > gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt
      timeout -k 10 520 python tools/dev/fuzz_parity.py 700 21000 --chained > gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt ;;
+  h) timeout -k 10 1080 python tools/dev/fuzz_parity.py 180 30000 --long > gpurun_out/r05_fuzz_parity_long_horizon_draws_30000_30179.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_long_horizon_draws_30000_30179.txt ;;
 esac
