@@ -1,6 +1,7 @@
 #!/bin/bash
 # round 5: the three parity campaigns of rounds 3-4 re-run on the build that carries its slacks (5160 draws: seeds 0-459, 1000-2199, 3000-6499),
 # in chunks that fit one GPU call each:  gpurun -- bash tools/dev/r05_fuzz.sh <a|b|c|d>
+# (i), (j): last campaigns of the round on the final tree, all kinds, seeds no build has seen
 # (h): horizons 160 .. 600 on the random vehicles (the block-parallel tail; batches <= 65)
 # (g): the two other warm starts of the fuzzer - an arbitrary, dynamically inconsistent linearisation trajectory; each side's own result - on new seeds
 # (e), (f): late in the round, two more campaigns on seeds no build has seen (10000-13599)
@@ -22,4 +23,11 @@ case "$1" in
   g) timeout -k 10 520 python tools/dev/fuzz_parity.py 700 20000 --random-init > gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_random_init_draws_20000_20699.txt
      timeout -k 10 520 python tools/dev/fuzz_parity.py 700 21000 --chained > gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_chained_draws_21000_21699.txt ;;
   h) timeout -k 10 1080 python tools/dev/fuzz_parity.py 180 30000 --long > gpurun_out/r05_fuzz_parity_long_horizon_draws_30000_30179.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_long_horizon_draws_30000_30179.txt ;;
+  i) timeout -k 10 1080 python tools/dev/fuzz_parity.py 2500 40000 > gpurun_out/r05_fuzz_parity_draws_40000_42499.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_draws_40000_42499.txt ;;
+  j) timeout -k 10 300 python tools/dev/fuzz_parity.py 200 31000 --long > gpurun_out/r05_fuzz_parity_long_horizon_draws_31000_31199.txt 2>&1; tail -1 gpurun_out/r05_fuzz_parity_long_horizon_draws_31000_31199.txt
+     timeout -k 10 200 python tools/dev/fuzz_perm.py 200 2000 > gpurun_out/r05_fuzz_permutation_draws_2000_2199.txt 2>&1; tail -1 gpurun_out/r05_fuzz_permutation_draws_2000_2199.txt
+     timeout -k 10 150 python tools/dev/fuzz_f32io.py 150 2000 > gpurun_out/r05_fuzz_f32io_draws_2000_2149.txt 2>&1; tail -1 gpurun_out/r05_fuzz_f32io_draws_2000_2149.txt
+     timeout -k 10 120 python tools/dev/fuzz_nan.py 150 2000 > gpurun_out/r05_fuzz_nan_isolation_draws_2000_2149.txt 2>&1; tail -1 gpurun_out/r05_fuzz_nan_isolation_draws_2000_2149.txt
+     timeout -k 10 100 python tools/dev/fuzz_parity.py 120 9000 --lane > gpurun_out/r05_fuzz_lane_kernel_draws_9000_9119.txt 2>&1; tail -1 gpurun_out/r05_fuzz_lane_kernel_draws_9000_9119.txt
+     timeout -k 10 100 python tools/dev/fuzz_parity.py 60 9200 --cond > gpurun_out/r05_fuzz_condensed_kernel_draws_9200_9259.txt 2>&1; tail -1 gpurun_out/r05_fuzz_condensed_kernel_draws_9200_9259.txt ;;
 esac
