@@ -399,7 +399,7 @@ def main() -> None:
     solver = NmpcOcpSolver(cfg)
     hover = cfg.mass * cfg.gravity / 4.0
     # seed 0 = config 2 (the headline), 100 + rank = config 4 (multi-GPU); --seed 1 / 5 give the samples of configs 3 / 5
-    seed = args.seed if args.seed is not None else (0 if world == 1 else 100 + rank)
+    seed = (args.seed + (rank if world > 1 else 0)) if args.seed is not None else (0 if world == 1 else 100 + rank)   # (shards stay distinct)
     dist_kw = NEAR_HOVER if args.dist == "near_hover" else AGGRESSIVE
     x0_h = sample_x0(B, seed, **dist_kw)
     yref_h, yref_e_h = hover_reference(N, hover)
