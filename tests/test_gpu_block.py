@@ -160,6 +160,30 @@ def test_block_parallel_tail_gives_the_results_of_the_sequential_work_list(N, B,
         np.testing.assert_allclose(b2["u0"][ok2], a2["u0"][ok2], rtol=0, atol=1e-9)
 
 
+@pytest.mark.parametrize("seed", [30001, 30003, 30004, 30005])
+def test_long_horizons_on_random_vehicles_against_the_oracle(seed):
+    """Four draws of the long-horizon fuzz (tools/dev/fuzz_parity.py --long, profiles/r05_fuzz_parity_long_horizon_draws_*: horizons
+    200 / 320 / 400 / 600 on random vehicles, tunings and references; wild and aggressive initial states, shared and per-stage
+    linearisation, up to 32 passes, interior-point endings and failed instances among them): the block-parallel tail against the oracle,
+    cold and warm-started - statuses equal on every instance, commands of the solved ones to 1e-8 of the hover thrust."""
+    from oracle import oracle as O
+    from rotors_mpc_controller_amd.solver import NmpcOcpSolver
+    from tests.fuzz_draws import draw, oracle_config
+    over, x0, yref, ye, hov, _, _ = draw(seed, horizons=[160, 200, 256, 320, 400, 600], max_batch=65)
+    s = NmpcOcpSolver(_lib.default_config(**over))
+    c = oracle_config(s.config, qp_polish=1)
+    out = s.solve_batch(x0, yref, ye, want_traj=True)
+    assert s.tail_states(len(x0))[0] > 0                     # the handle has the block-parallel tail (N >= 160)
+    ref = O.solve_batch(c, x0, yref, ye, want_traj=True, nthreads=8)
+    out2 = s.solve_batch(x0, yref, ye, x_init=ref["x"], u_init=ref["u"])
+    ref2 = O.solve_batch(c, x0, yref, ye, x_init=ref["x"], u_init=ref["u"], nthreads=8)
+    for o, r in ((out, ref), (out2, ref2)):
+        np.testing.assert_array_equal(o["status"], r["status"])
+        ok = r["status"] == 0
+        assert ok.any() and np.abs(o["u0"][ok] - r["u0"][ok]).max() <= 1e-8 * max(1.0, hov)
+    s.close()
+
+
 def test_block_parallel_tail_on_a_per_stage_linearisation_at_the_long_horizon(monkeypatch):
     """N = 600 without the shared cold-start linearisation (what a warm-started tick runs): tail against sequential work list."""
     N, B = 600, 256
