@@ -9,7 +9,9 @@ active-set / interior-point QP -> full SQP step) with the inputs already residen
 the first-stage commands u0 (the only exchange the path has) are moved by RCCL all-gathers, one per
 group of --gather-every consecutive ticks, asynchronously to the following solves.
 Workload = BASELINE.json configs[1]: B = 4096 near-hover initial states per GPU, horizon 20,
-FP64, hover reference materialised per instance ([B,N,17]).
+FP64, hover reference materialised per instance ([B,N,17]), x0 sample of seed 0 (config 2).
+The other configs of the survey are flags: config 3 `--batch 65536 --dtype f32io --seed 1`, config 5 `--batch 1024 --horizon 600 --seed 5`
+(tools/bench_table.sh runs them all).
 """
 from __future__ import annotations
 
