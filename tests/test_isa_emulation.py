@@ -218,6 +218,17 @@ def test_emulator_treats_vcc_as_an_ordinary_register_pair(tmp_path):
     assert (w.R[5] == 5).all() and int(w.S[107]) == 0
 
 
+def test_emulator_runs_the_sdwa_form_of_an_integer_add(tmp_path):
+    """v_add_u32_sdwa with a byte select (how the compiler adds a bool to an integer: npol hand-over of nmpc_team_as.hpp)."""
+    w, out = _run_snippet(tmp_path, """
+\tv_mov_b32_e32 v1, 0x10203
+\tv_mov_b32_e32 v2, 7
+\tv_add_u32_sdwa v3, v2, v1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0
+\tv_add_u32_sdwa v4, v2, v1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1
+\tv_add_u32_sdwa v5, v2, v1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1""")
+    assert not w.viol and (w.R[3] == 10).all() and (w.R[4] == 9).all() and (w.R[5] == 8).all()
+
+
 def test_emulator_checks_scratch_against_the_private_segment_and_its_spills(tmp_path):
     body = """
 \tv_mov_b32_e32 v1, 7

@@ -1128,6 +1128,24 @@ def _v_cmp_sdwa(w, ins):
     w.ws(ins.ops[0], w.mask_to_bits(res & w.mask()), 64)
 
 
+def _v_int2_sdwa(w, ins):
+    """v_<op>_sdwa vD, src0, src1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:<sel> src1_sel:<sel>: the VOP2 integer operation on a byte /
+    word / dword of each source (zero-extended); only a whole-dword destination is written by the compiler in these kernels."""
+    if ins.mods.get("dst_sel", "DWORD") != "DWORD":
+        raise EmuError(f"line {ins.line}: {ins.text} (dst_sel other than DWORD)")
+    base = re.fullmatch(r"v_(\w+)_sdwa", ins.op).group(1)
+    a = _sdwa_sel(w.rv32(ins.ops[1]), ins.mods.get("src0_sel"))
+    b = _sdwa_sel(w.rv32(ins.ops[2]), ins.mods.get("src1_sel"))
+    if base == "add_u32": r = a + b
+    elif base == "sub_u32": r = a - b
+    elif base == "and_b32": r = a & b
+    elif base == "or_b32": r = a | b
+    elif base == "lshlrev_b32": r = b << (a & np.uint32(31))
+    elif base == "lshrrev_b32": r = b >> (a & np.uint32(31))
+    else: raise EmuError(f"line {ins.line}: {ins.text}")
+    w.wv32(ins.ops[0], r.astype(np.uint32))
+
+
 def _v_addsub_co(w, ins):
     d, sd, a, b = ins.ops[:4]
     x, y = w.rv32(a).astype(np.uint64), w.rv32(b).astype(np.uint64)
@@ -1280,6 +1298,7 @@ _PATTERNS = [
     (r"ds_write2?_b(32|64|128)", _ds_write),
     (r"ds_bpermute_b32", _ds_bpermute),
     (r"v_cmp_\w+_[ui](16|32)_sdwa", _v_cmp_sdwa),
+    (r"v_(add_u32|sub_u32|and_b32|or_b32|lshlrev_b32|lshrrev_b32)_sdwa", _v_int2_sdwa),
     (r"v_(add|sub)_co_u32_e64", _v_addsub_co),
     (r"v_mul_hi_(i32|u32)(_e64)?", _v_mul_hi),
     (r"v_mul_i32_i24(_e32|_e64)?", _v_mul_i32_i24),
