@@ -891,7 +891,6 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
     double rho = 1.0, mu = 0.0, pol_mu = c->qp_polish_mu;
     double gbase = 0.0, growth = 0.0, step_last = 0.0;
     int polished = 0, npolish = 0, untrusted = 0;
-    int pol_untrusted = 0;  /* the certificate refused an active-set attempt: only an accepted pass may still end the solve with status 0 (below) */
     int warm_derived = 0;   /* the iterate descends from a warm start (an exhausted attempt's last pass), not from the cold point */
     const int itmax = c->qp_iter_max > 0 ? c->qp_iter_max : 1;
     int pol_passes, pol_budget;
@@ -921,7 +920,7 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
                              (c->qp_warm_start && !last_attempt) ? &warm : NULL)) {
                 polished = 1; mu = 0.0; rho = 0.0; break;
             }
-            if (trip) { untrusted = 1; pol_untrusted = 1; npolish = pol_budget; }     /* the same pins would fail the same way: no further attempt */
+            if (trip) { untrusted = 1; npolish = pol_budget; }     /* the same pins would fail the same way: no further attempt */
             pol_mu *= 1e-2;
             if (warm) {      /* the iterate was replaced: its duality measure, and nothing known about its stationarity */
                 mu = 0.0;
@@ -1080,11 +1079,6 @@ static int ocpqp_ipm(const orc_config *c, const ocpqp *p, const double *dx0,
         rho *= (1.0 - alpha);
         if (getenv("ORC_DEBUG")) fprintf(stderr, "it %d mu %.3e aaff %.3e muaff %.3e sg %.3e alpha %.3e rho %.3e\n", it, mu, aaff, muaff, sg, alpha, rho);
     }
-    /* Once the certificate has refused an active-set attempt, only an ACCEPTED pass can end the solve with status 0: the certificate
-     * measures later factorisations against the first one of the solve, not that one's own conditioning, and the convergence test above
-     * follows tracked residuals - after a refused attempt the iterate can read "converged", or the (tolerated) iteration cap be reached,
-     * on numbers that are not a solution (fuzz draw 42412 instance 133: res_stat 2.6e22 with status 0; kernels: end of team_as) */
-    if (pol_untrusted && !polished && (status == 0 || status == 2)) status = 4;
     /* final rollout of the states from the inputs (dynamics are affine) */
     if (!polished) ipm_rollout(p, dx0, u, x);
     if (st) {

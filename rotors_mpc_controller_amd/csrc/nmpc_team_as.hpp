@@ -383,8 +383,6 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     // team-wide value of the FIRST factorisation of the solve (0 = none yet)
     T gm = 0, gbase = 0;
     bool tripped = false;    // the certificate ended an attempt of this team: no further attempt is made
-    bool pol_tripped = false;   // ... an ACTIVE-SET attempt (carried through every hand-over as |npol| = budget + 1): from then on the solve may end
-                                // status 0 on an accepted pass only - see the end of this function
     bool from_ua = MODE == 0; // the result is an accepted active-set solution (candidate inputs, xhat of its forward sweep)
     // interior-point iteration (IPMK kernels): scalars of the corrector
     T sigmu = 0;
@@ -1154,7 +1152,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
             // be the pinned recursion itself - a long saturated stretch of an unstable plant is an open loop, P grows by rho(A)^2 per stage
             pol_fail = true;                            // give up this attempt
         }
-        if (trip) { pol_fail = true; tripped = true; pol_tripped = true; }  // not accurate enough to be accepted (see qp_growth_max): the attempt fails
+        if (trip) { pol_fail = true; tripped = true; }  // not accurate enough to be accepted (see qp_growth_max): the attempt fails
         pol2 = mode == M_POL;
 
         viol = false; heavy = false; kchgB = -1; xh = 0; anyp = false;
@@ -1234,8 +1232,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         mode = M_DONE;
         if (tcx.phase == 0) {
             const bool mid = tstate == TS_AS;            // handed over in the middle of its first attempt: the row is complete
-            int np0 = w.npol[inst];
-            if (np0 == -(c.polish_budget + 1)) { pol_tripped = true; np0 = -c.polish_budget; }     // (the certificate ended the attempt)
+            const int np0 = w.npol[inst];
             const T gb0 = w.gbase[inst];
             if (!mid) { npol = np0 < 0 ? -np0 : np0; pass_in_attempt = 0; gbase = fabs(gb0); }
             pol_mu = c.polish_mu * (mid ? T(1) : T(1e-2));
@@ -1334,7 +1331,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
                 // would have written (the fallback list relies on it), and the warm start becomes the interior point's iterate
                 const bool ended = tstate == TS_AS && mode == M_GIVEUP && first_attempt;
                 if (ended && r == 0) {
-                    w.npol[inst] = -(tripped ? c.polish_budget + (pol_tripped ? 1 : 0) : npol);
+                    w.npol[inst] = -(tripped ? c.polish_budget : npol);
                     w.gbase[inst] = warm_avail ? -gbase : gbase;
                 }
                 const bool install = ended && warm_avail;
@@ -1382,8 +1379,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         const bool attempt_first = MODE == 1 && c.polish && c.polish_budget > 0 && c.polish_passes > 0 && c.polish_mu >= c.mu0;
         bool first_free = attempt_first; // wave-uniform: the first active-set phase starts from "all inputs free"
         if (MODE == 2) {                 // the first attempt was made - and given up - by the active-set kernel
-            int np0 = w.npol[inst];
-            if (np0 == -(c.polish_budget + 1)) { pol_tripped = true; np0 = -c.polish_budget; }     // (the certificate ended the attempt)
+            const int np0 = w.npol[inst];
             npol = np0 < 0 ? -np0 : np0;
             pol_mu *= T(1e-2);
             const T gb0 = w.gbase[inst];
@@ -1523,13 +1519,6 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
     NMPC_STAMP(6)
     int nlp_status = status;
     if constexpr (MODE != 0) {
-        // Once the certificate has refused an active-set attempt of the solve, only an ACCEPTED pass (exact KKT check, certified
-        // factorisation) can end it with status 0.  The certificate measures later factorisations against the first one of the solve, not
-        // that one's own conditioning, and the interior point's convergence test follows tracked residuals: after a refused attempt its
-        // iterate can read "converged" - or the tolerated iteration cap be reached - on numbers that are not a solution (fuzz draw 42412
-        // instance 133: true stationarity residual 2.6e22, commands 1e-2 apart between the kernels and the oracle, status 0 on both
-        // sides until late round 5).  Oracle: ocpqp_ipm, pol_untrusted.
-        if (pol_tripped && !from_ua && (status == 0 || status == 2)) status = 4;
         // QP status -> acados numbering (oracle orc_sqp_rti): iteration cap tolerated or reported (U10 switch), min step -> QP failure
         nlp_status = status == 2 ? (c.maxiter_status ? 2 : 0) : (status == 3 ? 4 : status);
         const bool need_roll = MODE != 3 && valid && !from_ua && nlp_status == 0;
@@ -1573,7 +1562,7 @@ __device__ __forceinline__ bool team_as(const Consts<double> &c, const Work<doub
         if (r == 0) {
             // the continuation (work-list launch, or MODE 2 on this wave) resumes the pass budget from here (all of it spent when the
             // growth certificate ended the attempt: the same pins would fail the same way) and compares against the same first factorisation
-            w.npol[inst] = -(tripped ? c.polish_budget + (pol_tripped ? 1 : 0) : npol);
+            w.npol[inst] = -(tripped ? c.polish_budget : npol);
             w.gbase[inst] = warm_avail ? -gbase : gbase;     // < 0: the attempt ran out of passes, its last pass seeds the interior point
             if (!tcx.inplace) {
                 const int slot = atomicAdd(wl.count, 1);
