@@ -366,13 +366,14 @@ def main() -> None:
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
-        # RCCL prints a version banner on STDOUT when its communicator comes up (the first collective): keep this process's stdout
-        # for the ONE JSON line of the contract - C-level writes go to stderr until the communicator exists
+        # RCCL prints a version banner on STDOUT when its communicator comes up - inside init_process_group when a device_id is given (eager
+        # initialisation; found late in round 5: the banner stood in front of the JSON line of a one-rank rehearsal), at the first collective
+        # otherwise: keep this process's stdout for the ONE JSON line of the contract - C-level writes go to stderr until the communicator exists
         sys.stdout.flush()
         _saved_stdout = os.dup(1)
         os.dup2(2, 1)
         try:
+            dist.init_process_group("nccl", device_id=dev, rank=rank, world_size=world)
             _w = torch.zeros(1, device=dev)
             dist.all_reduce(_w)
             torch.cuda.synchronize(dev)

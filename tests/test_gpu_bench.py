@@ -18,7 +18,9 @@ def _run(extra_env, *args):
     out = subprocess.run([sys.executable, str(ROOT / "bench.py"), *args], capture_output=True, text=True, timeout=600,
                          cwd=str(ROOT), env=env)
     assert out.returncode == 0, out.stderr[-2000:]
-    return json.loads(out.stdout.strip().splitlines()[-1])
+    lines = out.stdout.strip().splitlines()
+    assert len(lines) == 1, lines[:3]               # the contract: ONE JSON line on stdout (no library banner in front of it)
+    return json.loads(lines[-1])
 
 
 def test_default_line_carries_the_contract_fields():
